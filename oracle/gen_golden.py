@@ -139,7 +139,7 @@ def run_case(R, case):
                 edge_uv=edge_uv, edge_w=edge_w, hops=hops)
     meta = dict(name=name, qasm=qf, topology=topo, nx=nxx, ny=nyy, cap=cap, weight_range=list(wr),
                 arch_seed=seed, Q=len(allq), C=C, T=len(ts), G=G, placers={},
-                nodes_are_range=bool(nodes == list(range(C))),
+                nodes_are_range=bool(nodes == list(range(C))), qubits=[str(q) for q in allq],
                 edge_w_hex=[float(w).hex() for w in edge_w])
 
     lsap_rec = []

@@ -1,0 +1,174 @@
+"""The CPU restatement (oracle/placer_oracle.py) against fixtures produced by the reference itself."""
+import random
+
+import numpy as np
+import pytest
+
+from conftest import ALL_CASES, SMALL_CASES, load_case
+from oracle import placer_oracle as O
+
+BIG = [c for c in ALL_CASES if c not in SMALL_CASES]
+
+
+def _rows_eq(rows, arr):
+    got = np.array([[0xFF if c is None else c for c in r] for r in rows], np.uint8)
+    return got.shape == arr.shape and bool((got == arr).all())
+
+
+@pytest.mark.parametrize("name", ALL_CASES)
+def test_timeslices_match_reference(name):
+    gc = load_case(name)
+    assert O.timeslices(gc.gate_q) == gc.slices
+
+
+@pytest.mark.parametrize("name", ALL_CASES)
+def test_distance_matrix_bits(name):
+    gc = load_case(name)
+    D = np.array(O.distance_matrix(gc.C, gc.edges))
+    assert D.tobytes() == gc.D.tobytes()
+    H = np.array(O.hop_matrix(gc.C, gc.edges))
+    assert (H == gc.hops).all()
+
+
+@pytest.mark.parametrize("name", ALL_CASES)
+def test_cost_v3_bits(name):
+    gc = load_case(name)
+    D = gc.D.tolist()
+    for p in ("HQA", "TRHQA", "GTRHQA"):
+        if gc.has(p):
+            got = O.cost_v3(gc.slices, gc.gate_q, gc.gate_mr, gc.part(p).tolist(), D)
+            assert float(got).hex() == gc.meta["placers"][p]["cost_hex"], p
+
+
+@pytest.mark.parametrize("name", ALL_CASES)
+def test_cost_v2_and_v1_bits(name):
+    gc = load_case(name)
+    D = gc.D.tolist()
+    for p in ("BFS", "RANDOM"):
+        pm = gc.meta["placers"][p]
+        rows = gc.part_rows(p)
+        try:
+            got = O.cost_v2(gc.slices, gc.gate_q, gc.gate_mr, rows, D)
+            assert pm["cost_error"] is None
+            assert float(got).hex() == pm["cost_hex"], p
+        except O.CostError as e:
+            assert pm["cost_error"] == str(e)
+        try:
+            got = O.cost_v1(gc.slices, gc.gate_q, gc.gate_mr, rows, D)
+            assert pm["v1_error"] is None
+            assert float(got) == gc.cost_v1(p), p
+        except O.CostError as e:
+            assert pm["v1_error"] == str(e)
+    for p in ("HQA", "GTRHQA"):
+        if gc.has(p):
+            got = O.cost_v1(gc.slices, gc.gate_q, gc.gate_mr, gc.part_rows(p), D)
+            assert float(got) == gc.cost_v1(p), p
+
+
+@pytest.mark.parametrize("name", ALL_CASES)
+def test_lsap_matches_scipy_records(name):
+    gc = load_case(name)
+    n = 0
+    for tag, cm, r, c in gc.lsap_samples():
+        rr, cc = O.lsap(cm.tolist())
+        assert rr == r.tolist() and cc == c.tolist(), (tag, cm.shape)
+        n += 1
+    if gc.has("HQA") and gc.meta["placers"]["HQA"]["n_lsap"]:
+        assert n > 0
+
+
+def test_lsap_random_against_scipy():
+    scipy_opt = pytest.importorskip("scipy.optimize")
+    rng = np.random.default_rng(5)
+    for trial in range(300):
+        nr, nc = rng.integers(1, 9, size=2)
+        if trial % 3 == 0:
+            cm = rng.integers(0, 3, size=(nr, nc)).astype(float)  # heavy ties
+        elif trial % 3 == 1:
+            cm = np.maximum(0.1, rng.normal(0.3, 0.5, size=(nr, nc)))  # clamp ties like the placers
+        else:
+            cm = rng.random((nr, nc))
+        r, c = scipy_opt.linear_sum_assignment(cm)
+        rr, cc = O.lsap(cm.tolist())
+        assert rr == r.tolist() and cc == c.tolist(), cm
+
+
+@pytest.mark.parametrize("name", SMALL_CASES)
+@pytest.mark.parametrize("placer", ["HQA", "TRHQA", "GTRHQA"])
+def test_place_hqa_family_small(name, placer):
+    _check_place(name, placer)
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("name", [c for c in BIG if "gen256" not in c])
+@pytest.mark.parametrize("placer", ["HQA", "TRHQA", "GTRHQA"])
+def test_place_hqa_family_big(name, placer):
+    _check_place(name, placer)
+
+
+def _check_place(name, placer):
+    gc = load_case(name)
+    if not gc.has(placer):
+        pytest.skip("capacity too small for this placer in the fixture")
+    D = gc.D.tolist()
+    if placer == "GTRHQA":
+        rows = O.place_gtrhqa(gc.slices, gc.gate_q, gc.gate_mr, gc.Q, gc.C, gc.cap, D)
+    else:
+        rec = []
+        rows = O.place_hqa_family(gc.slices, gc.gate_q, gc.gate_mr, gc.Q, gc.C, gc.cap, D, placer.lower(), rec)
+        # every recorded matrix the reference handed to scipy must occur, entry for entry
+        mine = {(len(m), np.array(m).tobytes()) for _, _, _, m in rec}
+        for tag, cm, r, c in gc.lsap_samples():
+            if tag == placer:
+                assert (cm.shape[0], cm.tobytes()) in mine, (name, placer)
+    assert _rows_eq(rows, gc.part(placer))
+
+
+@pytest.mark.parametrize("name", SMALL_CASES + ["test500_mesh8x8_u"])
+def test_place_random_and_bfs(name):
+    gc = load_case(name)
+    D = gc.D.tolist()
+    keys = gc.qubit_objects()
+    rng = random.Random()
+    rng.seed(gc.meta["placers"]["BFS"]["place_seed"])
+    rows = O.place_bfs(gc.slices, gc.gate_q, gc.Q, gc.C, gc.cap, gc.edges, D, qubit_key=keys, rng=rng)
+    assert _rows_eq(rows, gc.part("BFS"))
+    rng.seed(gc.meta["placers"]["RANDOM"]["place_seed"])
+    rows = O.place_random(gc.slices, gc.gate_q, gc.Q, gc.C, gc.cap, qubit_key=keys, rng=rng)
+    assert _rows_eq(rows, gc.part("RANDOM"))
+
+
+def test_known_answer_386():
+    """results.csv:2 of the reference: HQA == TRHQA == 386 x (the single edge weight) on the shipped
+    example config; with unit weight the shipped code gives exactly 386."""
+    gc = load_case("gen256_mesh2x1_i")
+    assert gc.cost("HQA") == 386.0 and gc.cost("TRHQA") == 386.0
+    D = gc.D.tolist()
+    assert O.cost_v3(gc.slices, gc.gate_q, gc.gate_mr, gc.part("HQA").tolist(), D) == 386.0
+    published = 769.4877543309925
+    assert abs(published / 386 - 1.99349) < 1e-5  # an edge weight inside the config's [1, 2]
+
+
+def test_qubo_energy_tiny_bruteforce():
+    """2 qubits joined by one gate, 2 cores, capacity 2, one slice: the minimum-energy states put both
+    qubits on one core with two slack bits set there."""
+    slices = [[0]]
+    gate_q = [(0, 1)]
+    act, inter = O.qubo_slices(slices, gate_q, ["q[0]", "q[1]"])
+    C, cap = 2, 2
+    H = [[0, 1], [1, 0]]
+    best, arg = None, []
+    for bits in range(1 << 8):
+        x = [[[(bits >> (j * 2 + i)) & 1 for i in range(2)] for j in range(C)]]
+        y = [[[(bits >> (4 + j * 2 + p)) & 1 for p in range(cap)] for j in range(C)]]
+        e = O.qubo_energy(act, inter, C, cap, H, x, y)
+        if best is None or e < best:
+            best, arg = e, [(x, y)]
+        elif e == best:
+            arg.append((x, y))
+    assert best == 0
+    for x, y in arg:
+        cores = [j for j in range(C) if x[0][j][0]]
+        assert len(cores) == 1 and x[0][cores[0]][1] == 1
+        assert sum(y[0][cores[0]]) == 2
+        assert O.qubo_decode(act, C, cap, x, 2) == [[cores[0], cores[0]]]
