@@ -1,0 +1,171 @@
+/*
+ * qplace.h — C ABI of libqplace.so: the MI355X (gfx950) placement-cost engine.
+ *
+ * The reference (surankan-de/quantum-simulator) is pure Python and has no FFI; its plug-in seam is
+ * the pair of methods every placer exposes (main.py:85-97):
+ *     place_per_timeslice(circuit, multicore_arch) -> list[dict[qubit -> core]]
+ *     per_timeslice_cost(circuit, partition, multicore_arch) -> float
+ * Each entry point below replaces one piece of what those methods compute; the comment on each names
+ * the reference lines it stands in for.  INTEGRATION.md shows the ctypes stub a maintainer of the
+ * reference would add to its placers.
+ *
+ * Conventions
+ *  - Plain pointers and sizes only.  "dev" pointers are HIP device memory owned by the caller;
+ *    "host" pointers are ordinary memory.  The library never allocates device memory.
+ *  - Every function returns QP_OK (0) or a negative QP_E* code; qp_last_error() then holds a message
+ *    (thread-local).  Nothing throws or exits across the ABI.
+ *  - Device entry points take a hipStream_t as void* and are asynchronous with respect to the host;
+ *    the caller selects the device (hipSetDevice) before the call.
+ *  - Core ids are uint8 (C <= 255 real cores + 0xFF = "qubit not in this slice's dict").
+ */
+#ifndef QPLACE_H
+#define QPLACE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QP_VERSION 100
+
+#define QP_OK 0
+#define QP_EINVAL (-1)   /* bad argument (shape, alignment, range) */
+#define QP_EHIP (-2)     /* a HIP runtime call failed */
+#define QP_ENOSPC (-3)   /* caller-provided buffer or workspace too small */
+#define QP_EINFEASIBLE (-4) /* assignment problem has no finite solution */
+
+#define QP_ABSENT 0xFF
+
+/* One counted two-qubit gate (not Measure/Reset) of timeslice t, in the reference's slice order
+ * (Placer.py:14-61 decides membership and order; HQA_placer.py:66-67 decides "counted"). */
+typedef struct QpEdge {
+    uint16_t u, v; /* qubit indices = positions in circuit.qubits (HQA_placer.py:32) */
+    int32_t t;     /* timeslice */
+} QpEdge;
+
+/* One (timeslice, gate, qubit) visit of the gate-ordered walk the BFS/Random/QUBO/Base cost functions
+ * do (BFS_placer.py:214-237).  prev_t is the previous timeslice in which the same qubit was visited
+ * (-1: none): "last" in those loops is the assignment at that slice. */
+typedef struct QpVisit {
+    uint16_t q;       /* this qubit */
+    uint16_t partner; /* the gate's other qubit if this is the first qubit of a counted two-qubit gate,
+                         else 0xFFFF */
+    int32_t t;
+    int32_t prev_t;
+    int32_t pad_;
+} QpVisit;
+
+/* Device-resident circuit tables (all pointers dev, built once per circuit by the host side). */
+typedef struct QpCircuit {
+    int32_t Q;  /* qubits */
+    int32_t T;  /* timeslices */
+    int32_t nE; /* counted two-qubit gates */
+    int32_t nV; /* visits */
+    const int32_t* slice_edge_ptr;  /* [T+1] CSR over edges */
+    const QpEdge* edges;            /* [nE] */
+    const int16_t* lookahead;       /* [nE*6] other-qubit of the <=2 two-qubit commands that touch
+                                       (u,v) in slices t+1, t+2, t+3 (slots 2k, 2k+1 = slice t+1+k, in
+                                       slice order), -1 = empty (HQA_placer.py:227-237) */
+    const int32_t* slice_visit_ptr; /* [T+1] CSR over visits */
+    const QpVisit* visits;          /* [nV] */
+} QpCircuit;
+
+/* Distance table as the kernels consume it. */
+#define QP_DT_F64 0 /* C*C doubles, row = source core */
+#define QP_DT_U16 1 /* C*C uint16: every finite entry is an integer <= 65534 (integer edge weights) */
+typedef struct QpDTable {
+    int32_t kind;
+    int32_t C;
+    const void* table; /* dev, C*C entries, row-major, zero diagonal */
+} QpDTable;
+
+int qp_version(void);
+const char* qp_last_error(void);
+
+/* ---------------------------------------------------------------- host-side pieces */
+
+/* All-pairs core distances, host.  Row i is a Dijkstra from source i that accumulates dist[u] + w
+ * outwards; unreachable pairs fall back to hop counts, then +inf; the diagonal is 0.
+ * Replaces BasePlacer.get_weighted_distance (Placer.py:63-76) and the C*C fills built on it
+ * (HQA_placer.py:47-54, TRHQA_placer.py:51-59, GTRHQA_placer.py:51-58). */
+int qp_apsp_f64(int32_t C, int32_t n_edges, const int32_t* eu, const int32_t* ev, const double* w,
+                double* D_out /* host [C*C] */);
+
+/* Unweighted hop counts as doubles (+inf when unreachable), host.  Replaces the
+ * nx.shortest_path_length calls without weight (Qubo_placer.py:35-38,192,201). */
+int qp_hops_f64(int32_t C, int32_t n_edges, const int32_t* eu, const int32_t* ev,
+                double* H_out /* host [C*C] */);
+
+/* Rectangular linear sum assignment, host; same result (including ties) as
+ * scipy.optimize.linear_sum_assignment (HQA_placer.py:126, TRHQA_placer.py:171).
+ * row_out/col_out receive min(nr,nc) pairs, rows ascending. */
+int qp_lsap_f64(int32_t nr, int32_t nc, const double* cost /* host [nr*nc] */, int32_t* row_out,
+                int32_t* col_out);
+
+/* n independent problems solved on `threads` host threads.  Problem k reads cost + k*stride (row pitch
+ * ld) with shape nr[k] x nc[k]; writes row_out/col_out + k*out_stride; status[k] is QP_OK or
+ * QP_EINFEASIBLE. */
+int qp_lsap_f64_batch(int32_t n, const int32_t* nr, const int32_t* nc, const double* cost, int64_t stride,
+                      int32_t ld, int32_t* row_out, int32_t* col_out, int32_t out_stride, int32_t* status,
+                      int32_t threads);
+
+/* Chooses the device representation of a host distance matrix and writes it into a host staging
+ * buffer the caller then copies to the device (C*C*8 bytes is always enough).  The diagonal is
+ * forced to 0 (the reference never adds a term for equal cores).  Returns the kind in *kind_out. */
+int qp_dtable_pack(const double* D_host, int32_t C, void* staging /* host */, size_t staging_bytes,
+                   int32_t* kind_out, size_t* bytes_out);
+
+/* ---------------------------------------------------------------- device: cost evaluation */
+
+/* Workspace (bytes, dev) qp_slice_cost_v3 / _v2 need for B partitions of circuit (T slices). */
+size_t qp_slice_cost_workspace(int32_t T, int64_t B);
+
+/* Total communication cost of B partitions of one circuit, HQA-family definition
+ * (HQA_placer.py:259-287 == TRHQA_placer.py:551-585 == GTRHQA_placer.py:358-383):
+ *   sum over slices i, counted gates (u,v) of slice i with A[i][u] != A[i][v]:  D[A[i][u]][A[i][v]]
+ * + sum over i = 2..T-1, all qubits q with A[i][q] != A[i-1][q]:                 D[A[i-1][q]][A[i][q]]
+ * A: dev uint8 [B][Tp][ldq] (Tp >= T rows per partition, row pitch ldq >= Q, ldq % 16 == 0); row i is
+ * used for slice i whatever Tp is (GTRHQA returns T+1 rows).  out: dev double [B].
+ * Sums are formed in a fixed order (bitwise reproducible run to run); exact when D is QP_DT_U16. */
+int qp_slice_cost_v3(const QpCircuit* circ, const QpDTable* dt, const uint8_t* A, int64_t B, int32_t Tp,
+                     int32_t ldq, double* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Gate-ordered cost of B sparse partitions (QP_ABSENT = qubit not in the slice's dict).
+ * flags selects the reference variant:
+ *   QP_V2  BFS_placer.py:202-239 == Random_placer.py:178-213
+ *   QP_V1  BasePlacer.per_timeslice_cost, Placer.py:78-120 (Tp may be < T: later slices are skipped)
+ *   QP_V4  Qubo_placer.py:177-207 (pass the hop-count table; movement is looked up as [cur][last])
+ * Where the reference would raise (absent qubit of a counted gate in V2/V4; a qubit placed at its
+ * previous visit and absent now) out[b] = +inf, which is what main.py:99-102 records for the repeat. */
+#define QP_V2 0
+#define QP_V1 1
+#define QP_V4 2
+int qp_slice_cost_v2(const QpCircuit* circ, const QpDTable* dt, const uint8_t* A, int64_t B, int32_t Tp,
+                     int32_t ldq, int32_t flags, double* out, void* workspace, size_t workspace_bytes,
+                     void* stream);
+
+/* ---------------------------------------------------------------- device: cost matrices */
+
+/* One op x core cost matrix per instance, for the current while-iteration of the placement loop.
+ * kind: QP_CM_HQA    HQA_placer.py:112-122 with :208-241
+ *       QP_CM_TRHQA  TRHQA_placer.py:135-166 with :471-532
+ *       QP_CM_GTRHQA GTRHQA_placer.py:99-112
+ * t[b]: current timeslice; a: dev uint8 [B][ldq] live assignment; ops: dev int32 [B][max_ops] indices
+ * into circ->edges; avail: dev uint8 [B][C] core ids (first n_avail[b] valid).
+ * cost_out: dev double [B][max_ops][C], entry [b][i][j] valid for i < n_ops[b], j < n_avail[b].
+ * The distance table must be QP_DT_F64.  Arithmetic is done one rounding at a time in the
+ * reference's order (no FMA contraction), so entries are bit-identical to the reference's. */
+#define QP_CM_HQA 0
+#define QP_CM_TRHQA 1
+#define QP_CM_GTRHQA 2
+int qp_cost_matrix(int32_t kind, const QpCircuit* circ, const QpDTable* dt, int64_t B, const int32_t* t,
+                   const uint8_t* a, int32_t ldq, const int32_t* ops, const int32_t* n_ops,
+                   int32_t max_ops, const uint8_t* avail, const int32_t* n_avail, double* cost_out,
+                   void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QPLACE_H */

@@ -432,7 +432,7 @@ def _make_space(a, occ, cap, C, D):
 
 def place_hqa_family(slices, gate_q, gate_mr, Q, C, cap, D, kind, record=None):
     """``kind`` 'hqa': HQA_placer.py:20-176; 'trhqa': TRHQA_placer.py:22-228.  Returns T rows.
-    ``record`` (a list) receives (t, ops, avail, matrix) for every LSAP call."""
+    ``record`` (a list) receives (t, ops, avail, matrix, live assignment) for every LSAP call."""
     if Q > C * cap:
         raise ValueError("Not enough space")
     T = len(slices)
@@ -465,7 +465,7 @@ def place_hqa_family(slices, gate_q, gate_mr, Q, C, cap, D, kind, record=None):
             else:
                 M = [[entry_trhqa(q1, q2, c, a, slices, gate_q, t, D) for c in avail] for _, q1, q2 in remaining]
             if record is not None:
-                record.append((t, list(remaining), list(avail), [list(r) for r in M]))
+                record.append((t, list(remaining), list(avail), [list(r) for r in M], list(a)))
             try:
                 rows, cols = lsap(M)
             except ValueError:
@@ -527,7 +527,7 @@ def place_gtrhqa(slices, gate_q, gate_mr, Q, C, cap, D, record=None):
             continue
         M = [[entry_gtrhqa(q1, q2, c, a, D) for c in avail] for _, q1, q2 in ops]
         if record is not None:
-            record.append((t, list(ops), list(avail), [list(r) for r in M]))
+            record.append((t, list(ops), list(avail), [list(r) for r in M], list(a)))
         nops, nav = len(ops), len(avail)
         core_free = [True] * nav
         op_left = [True] * nops

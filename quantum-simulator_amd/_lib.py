@@ -1,0 +1,84 @@
+"""ctypes binding of libqplace.so (declared in include/qplace.h).
+
+There is no fallback: if the shared library is missing or lacks a symbol, importing this module
+raises, and so does every call that needs it.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libqplace.so")
+
+QP_OK = 0
+QP_DT_F64, QP_DT_U16 = 0, 1
+QP_V2, QP_V1, QP_V4 = 0, 1, 2
+QP_CM_HQA, QP_CM_TRHQA, QP_CM_GTRHQA = 0, 1, 2
+QP_ABSENT = 0xFF
+
+
+class QpCircuit(C.Structure):
+    _fields_ = [("Q", C.c_int32), ("T", C.c_int32), ("nE", C.c_int32), ("nV", C.c_int32),
+                ("slice_edge_ptr", C.c_void_p), ("edges", C.c_void_p), ("lookahead", C.c_void_p),
+                ("slice_visit_ptr", C.c_void_p), ("visits", C.c_void_p)]
+
+
+class QpDTable(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("C", C.c_int32), ("table", C.c_void_p)]
+
+
+class QplaceError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libqplace error {code}: {msg}")
+        self.code = code
+
+
+EXPORTS = {
+    "qp_version": (C.c_int, []),
+    "qp_last_error": (C.c_char_p, []),
+    "qp_apsp_f64": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "qp_hops_f64": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "qp_lsap_f64": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "qp_lsap_f64_batch": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
+                                    C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]),
+    "qp_dtable_pack": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.POINTER(C.c_int32),
+                                 C.POINTER(C.c_size_t)]),
+    "qp_slice_cost_workspace": (C.c_size_t, [C.c_int32, C.c_int64]),
+    "qp_slice_cost_v3": (C.c_int, [C.POINTER(QpCircuit), C.POINTER(QpDTable), C.c_void_p, C.c_int64, C.c_int32,
+                                   C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "qp_slice_cost_v2": (C.c_int, [C.POINTER(QpCircuit), C.POINTER(QpDTable), C.c_void_p, C.c_int64, C.c_int32,
+                                   C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "qp_cost_matrix": (C.c_int, [C.c_int32, C.POINTER(QpCircuit), C.POINTER(QpDTable), C.c_int64, C.c_void_p,
+                                 C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_void_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library (loads it on first use)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it first (python -c 'import __graft_entry__ as g; g.build()'). "
+                "This package has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in EXPORTS.items():
+            fn = getattr(L, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != QP_OK:
+        raise QplaceError(rc, lib().qp_last_error().decode(errors="replace"))
+
+
+def ptr(arr):
+    """Address of a C-contiguous numpy array's data."""
+    if not arr.flags["C_CONTIGUOUS"]:
+        raise ValueError("array must be C-contiguous")
+    return arr.ctypes.data

@@ -1,0 +1,328 @@
+// Host-side pieces of libqplace.so: error plumbing, all-pairs distances, hop counts, the rectangular
+// assignment solver and the distance-table packer.  No device code here.
+#include "qplace_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <limits>
+#include <queue>
+#include <thread>
+#include <vector>
+
+namespace qp {
+
+static thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+}  // namespace qp
+
+extern "C" int qp_version(void) { return QP_VERSION; }
+extern "C" const char* qp_last_error(void) { return qp::g_err; }
+
+// ------------------------------------------------------------------------------------------------
+// Distances
+// ------------------------------------------------------------------------------------------------
+
+namespace {
+
+struct Adj {
+    std::vector<int32_t> ptr, nbr;
+    std::vector<double> w;
+};
+
+// Neighbour lists in edge-insertion order (u gets v, v gets u, edge by edge).
+int build_adj(int32_t C, int32_t nE, const int32_t* eu, const int32_t* ev, const double* w, Adj& a) {
+    a.ptr.assign(C + 1, 0);
+    for (int32_t e = 0; e < nE; ++e) {
+        if (eu[e] < 0 || eu[e] >= C || ev[e] < 0 || ev[e] >= C)
+            return qp::fail(QP_EINVAL, "edge %d endpoint out of range", e);
+        a.ptr[eu[e] + 1]++;
+        a.ptr[ev[e] + 1]++;
+    }
+    for (int32_t i = 0; i < C; ++i) a.ptr[i + 1] += a.ptr[i];
+    a.nbr.assign(a.ptr[C], 0);
+    a.w.assign(a.ptr[C], 0.0);
+    std::vector<int32_t> fill(a.ptr.begin(), a.ptr.end() - 1);
+    for (int32_t e = 0; e < nE; ++e) {
+        double we = w ? w[e] : 1.0;
+        a.nbr[fill[eu[e]]] = ev[e];
+        a.w[fill[eu[e]]++] = we;
+        a.nbr[fill[ev[e]]] = eu[e];
+        a.w[fill[ev[e]]++] = we;
+    }
+    return QP_OK;
+}
+
+void bfs_hops(const Adj& a, int32_t C, int32_t src, std::vector<int32_t>& hop) {
+    hop.assign(C, -1);
+    std::vector<int32_t> frontier{src}, next;
+    hop[src] = 0;
+    while (!frontier.empty()) {
+        next.clear();
+        for (int32_t u : frontier)
+            for (int32_t k = a.ptr[u]; k < a.ptr[u + 1]; ++k) {
+                int32_t v = a.nbr[k];
+                if (hop[v] < 0) {
+                    hop[v] = hop[u] + 1;
+                    next.push_back(v);
+                }
+            }
+        frontier.swap(next);
+    }
+}
+
+}  // namespace
+
+extern "C" int qp_apsp_f64(int32_t C, int32_t nE, const int32_t* eu, const int32_t* ev, const double* w,
+                           double* D) {
+    if (C <= 0 || nE < 0 || !D || (nE > 0 && (!eu || !ev || !w))) return qp::fail(QP_EINVAL, "qp_apsp_f64: bad argument");
+    Adj a;
+    if (int rc = build_adj(C, nE, eu, ev, w, a)) return rc;
+    const double INF = std::numeric_limits<double>::infinity();
+    std::vector<double> best(C);
+    std::vector<char> reached(C), done(C);
+    std::vector<int32_t> hop;
+    using Item = std::pair<double, int32_t>;
+    for (int32_t s = 0; s < C; ++s) {
+        // Each tentative distance is the rounded sum (distance of the settled node) + (edge weight), the
+        // settled value of a node is the smallest such sum: independent of how ties are popped.
+        std::fill(reached.begin(), reached.end(), 0);
+        std::fill(done.begin(), done.end(), 0);
+        std::priority_queue<Item, std::vector<Item>, std::greater<Item>> pq;
+        best[s] = 0.0;
+        reached[s] = 1;
+        pq.push({0.0, s});
+        while (!pq.empty()) {
+            auto [d, u] = pq.top();
+            pq.pop();
+            if (done[u]) continue;
+            done[u] = 1;
+            for (int32_t k = a.ptr[u]; k < a.ptr[u + 1]; ++k) {
+                int32_t v = a.nbr[k];
+                if (done[v]) continue;
+                double nd = d + a.w[k];
+                if (!reached[v] || nd < best[v]) {
+                    reached[v] = 1;
+                    best[v] = nd;
+                    pq.push({nd, v});
+                }
+            }
+        }
+        bool need_hops = false;
+        for (int32_t j = 0; j < C; ++j) {
+            if (j == s) {
+                D[(size_t)s * C + j] = 0.0;
+            } else if (done[j]) {
+                double v = best[j];
+                D[(size_t)s * C + j] = std::isnan(v) ? INF : v;
+            } else {
+                need_hops = true;
+            }
+        }
+        if (need_hops) {
+            bfs_hops(a, C, s, hop);
+            for (int32_t j = 0; j < C; ++j)
+                if (j != s && !done[j]) D[(size_t)s * C + j] = hop[j] < 0 ? INF : (double)hop[j];
+        }
+    }
+    return QP_OK;
+}
+
+extern "C" int qp_hops_f64(int32_t C, int32_t nE, const int32_t* eu, const int32_t* ev, double* H) {
+    if (C <= 0 || nE < 0 || !H || (nE > 0 && (!eu || !ev))) return qp::fail(QP_EINVAL, "qp_hops_f64: bad argument");
+    Adj a;
+    if (int rc = build_adj(C, nE, eu, ev, nullptr, a)) return rc;
+    std::vector<int32_t> hop;
+    for (int32_t s = 0; s < C; ++s) {
+        bfs_hops(a, C, s, hop);
+        for (int32_t j = 0; j < C; ++j)
+            H[(size_t)s * C + j] = hop[j] < 0 ? std::numeric_limits<double>::infinity() : (double)hop[j];
+    }
+    return QP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Rectangular linear sum assignment (shortest augmenting paths, Crouse 2016), with the tie handling
+// that makes the result equal to scipy.optimize.linear_sum_assignment's.
+// ------------------------------------------------------------------------------------------------
+
+namespace {
+
+struct LsapScratch {
+    std::vector<double> u, v, spc, tcost;
+    std::vector<int32_t> path, col4row, row4col, remaining, order;
+    std::vector<char> SR, SC;
+};
+
+int lsap_solve(int32_t nr, int32_t nc, const double* cost, int32_t ld, int32_t* row_out, int32_t* col_out,
+               LsapScratch& s) {
+    if (nr == 0 || nc == 0) return QP_OK;
+    const bool transpose = nc < nr;
+    const double* c = cost;
+    int32_t cld = ld;
+    if (transpose) {
+        s.tcost.resize((size_t)nr * nc);
+        for (int32_t i = 0; i < nr; ++i)
+            for (int32_t j = 0; j < nc; ++j) s.tcost[(size_t)j * nr + i] = cost[(size_t)i * ld + j];
+        c = s.tcost.data();
+        cld = nr;
+        std::swap(nr, nc);
+    }
+    for (int32_t i = 0; i < nr; ++i)
+        for (int32_t j = 0; j < nc; ++j) {
+            double x = c[(size_t)i * cld + j];
+            if (std::isnan(x) || x == -std::numeric_limits<double>::infinity()) return QP_EINVAL;
+        }
+    const double INF = std::numeric_limits<double>::infinity();
+    s.u.assign(nr, 0.0);
+    s.v.assign(nc, 0.0);
+    s.spc.resize(nc);
+    s.path.assign(nc, -1);
+    s.col4row.assign(nr, -1);
+    s.row4col.assign(nc, -1);
+    s.remaining.resize(nc);
+    s.SR.resize(nr);
+    s.SC.resize(nc);
+    for (int32_t cur = 0; cur < nr; ++cur) {
+        double minval = 0.0;
+        int32_t i = cur, nrem = nc, sink = -1;
+        for (int32_t it = 0; it < nc; ++it) s.remaining[it] = nc - it - 1;
+        std::fill(s.SR.begin(), s.SR.end(), 0);
+        std::fill(s.SC.begin(), s.SC.end(), 0);
+        std::fill(s.spc.begin(), s.spc.end(), INF);
+        while (sink == -1) {
+            int32_t index = -1;
+            double lowest = INF;
+            s.SR[i] = 1;
+            const double* ci = c + (size_t)i * cld;
+            const double ui = s.u[i];
+            for (int32_t it = 0; it < nrem; ++it) {
+                int32_t j = s.remaining[it];
+                double r = minval + ci[j] - ui - s.v[j];
+                if (r < s.spc[j]) {
+                    s.path[j] = i;
+                    s.spc[j] = r;
+                }
+                // among equal tentative distances prefer a column that ends the search
+                if (s.spc[j] < lowest || (s.spc[j] == lowest && s.row4col[j] == -1)) {
+                    lowest = s.spc[j];
+                    index = it;
+                }
+            }
+            minval = lowest;
+            if (minval == INF) return QP_EINFEASIBLE;
+            int32_t j = s.remaining[index];
+            if (s.row4col[j] == -1) sink = j;
+            else i = s.row4col[j];
+            s.SC[j] = 1;
+            s.remaining[index] = s.remaining[--nrem];
+        }
+        s.u[cur] += minval;
+        for (int32_t r = 0; r < nr; ++r)
+            if (s.SR[r] && r != cur) s.u[r] += minval - s.spc[s.col4row[r]];
+        for (int32_t j = 0; j < nc; ++j)
+            if (s.SC[j]) s.v[j] -= minval - s.spc[j];
+        int32_t j = sink;
+        while (true) {
+            int32_t r = s.path[j];
+            s.row4col[j] = r;
+            std::swap(s.col4row[r], j);
+            if (r == cur) break;
+        }
+    }
+    if (transpose) {
+        s.order.resize(nr);
+        for (int32_t k = 0; k < nr; ++k) s.order[k] = k;
+        std::stable_sort(s.order.begin(), s.order.end(),
+                         [&](int32_t a, int32_t b) { return s.col4row[a] < s.col4row[b]; });
+        for (int32_t k = 0; k < nr; ++k) {
+            row_out[k] = s.col4row[s.order[k]];
+            col_out[k] = s.order[k];
+        }
+    } else {
+        for (int32_t k = 0; k < nr; ++k) {
+            row_out[k] = k;
+            col_out[k] = s.col4row[k];
+        }
+    }
+    return QP_OK;
+}
+
+}  // namespace
+
+extern "C" int qp_lsap_f64(int32_t nr, int32_t nc, const double* cost, int32_t* row_out, int32_t* col_out) {
+    if (nr < 0 || nc < 0 || ((nr > 0 && nc > 0) && (!cost || !row_out || !col_out)))
+        return qp::fail(QP_EINVAL, "qp_lsap_f64: bad argument");
+    LsapScratch s;
+    int rc = lsap_solve(nr, nc, cost, nc, row_out, col_out, s);
+    if (rc == QP_EINVAL) return qp::fail(rc, "qp_lsap_f64: matrix contains invalid numeric entries");
+    if (rc == QP_EINFEASIBLE) return qp::fail(rc, "qp_lsap_f64: cost matrix is infeasible");
+    return rc;
+}
+
+extern "C" int qp_lsap_f64_batch(int32_t n, const int32_t* nr, const int32_t* nc, const double* cost,
+                                 int64_t stride, int32_t ld, int32_t* row_out, int32_t* col_out,
+                                 int32_t out_stride, int32_t* status, int32_t threads) {
+    if (n < 0 || (n > 0 && (!nr || !nc || !cost || !row_out || !col_out || !status)))
+        return qp::fail(QP_EINVAL, "qp_lsap_f64_batch: bad argument");
+    for (int32_t k = 0; k < n; ++k)
+        if (nr[k] < 0 || nc[k] < 0 || nc[k] > ld || std::min(nr[k], nc[k]) > out_stride)
+            return qp::fail(QP_EINVAL, "qp_lsap_f64_batch: problem %d does not fit ld/out_stride", k);
+    threads = std::max(1, std::min(threads, n));
+    auto work = [&](int32_t tid) {
+        LsapScratch s;
+        for (int32_t k = tid; k < n; k += threads)
+            status[k] = lsap_solve(nr[k], nc[k], cost + (size_t)k * stride, ld, row_out + (size_t)k * out_stride,
+                                   col_out + (size_t)k * out_stride, s);
+    };
+    if (threads == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (int32_t tdx = 0; tdx < threads; ++tdx) pool.emplace_back(work, tdx);
+        for (auto& th : pool) th.join();
+    }
+    return QP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Distance-table packing
+// ------------------------------------------------------------------------------------------------
+
+extern "C" int qp_dtable_pack(const double* D, int32_t C, void* staging, size_t staging_bytes, int32_t* kind_out,
+                              size_t* bytes_out) {
+    if (!D || C <= 0 || C > 256 || !staging || !kind_out || !bytes_out)
+        return qp::fail(QP_EINVAL, "qp_dtable_pack: bad argument (C must be 1..256)");
+    const size_t n = (size_t)C * C;
+    bool integral = true;
+    for (size_t k = 0; k < n && integral; ++k) {
+        if (k / C == k % C) continue;
+        double x = D[k];
+        integral = std::isfinite(x) && x >= 0.0 && x <= 65534.0 && x == std::floor(x);
+    }
+    if (integral) {
+        if (staging_bytes < n * 2) return qp::fail(QP_ENOSPC, "qp_dtable_pack: staging too small");
+        uint16_t* o = static_cast<uint16_t*>(staging);
+        for (size_t k = 0; k < n; ++k) o[k] = (k / C == k % C) ? 0 : (uint16_t)D[k];
+        *kind_out = QP_DT_U16;
+        *bytes_out = n * 2;
+    } else {
+        if (staging_bytes < n * 8) return qp::fail(QP_ENOSPC, "qp_dtable_pack: staging too small");
+        double* o = static_cast<double*>(staging);
+        for (size_t k = 0; k < n; ++k) o[k] = (k / C == k % C) ? 0.0 : D[k];
+        *kind_out = QP_DT_F64;
+        *bytes_out = n * 8;
+    }
+    return QP_OK;
+}

@@ -1,0 +1,559 @@
+// Device side of libqplace.so: gfx950 kernels for placement-cost evaluation and op x core cost
+// matrices, plus their C-ABI launchers.  Built with -ffp-contract=off: the cost-matrix entries must
+// round exactly where the reference's Python floats round.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+
+#include "qplace_internal.h"
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return qp::fail(QP_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kLdsBytes = 160 * 1024;  // LDS per CU on gfx950; one workgroup may take all of it
+
+template <int KIND>
+struct Tab;
+template <>
+struct Tab<QP_DT_F64> {
+    using elem = double;
+    using acc = double;
+};
+template <>
+struct Tab<QP_DT_U16> {
+    using elem = uint16_t;
+    using acc = uint32_t;  // per work item: < 2^16 terms of < 2^16 each
+};
+
+__device__ inline double wave_sum(double x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, kWave);
+    return x;
+}
+__device__ inline double wave_sum(uint32_t x) {
+    unsigned long long v = x;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+    return (double)v;
+}
+
+// Copies the distance table into LDS (16 bytes per thread per step; the device buffer is padded to a
+// multiple of 16 bytes) and returns the padded size.
+__device__ inline uint32_t stage_table(uint8_t* smem, const void* table, uint32_t bytes) {
+    const uint32_t padded = (bytes + 15u) & ~15u;
+    const uint4* src = static_cast<const uint4*>(table);
+    uint4* dst = reinterpret_cast<uint4*>(smem);
+    for (uint32_t k = threadIdx.x; k < padded / 16; k += blockDim.x) dst[k] = src[k];
+    __syncthreads();
+    return padded;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Cost V3: dense partitions, HQA-family definition.
+//
+// Work item = (timeslice chunk, partition); item id = chunk * B + b so that the workgroups running
+// at one time read the same part of the circuit's edge list (it stays in L2) while each streams its
+// own contiguous rows of A.  One wave owns an item: it walks the rows in groups of G = 64*16/ldq rows
+// (one 16-byte load per lane), keeps the group plus the row before it in a private LDS strip
+// (movement compares a 16-byte piece with the piece one row pitch earlier; edge endpoints are byte
+// gathers from the strip), and looks every (core, core) pair up in the LDS-resident distance table.
+// The diagonal of the table is zero, so "add only if the cores differ" needs no compare.  Waves never
+// synchronise after the table is staged.
+// ------------------------------------------------------------------------------------------------
+
+constexpr int kV3Threads = 1024;
+constexpr int kV3Waves = kV3Threads / kWave;
+constexpr int kV3Ahead = 4;  // row groups in flight per wave beyond the one being processed
+
+struct V3Args {
+    const uint8_t* A;
+    const int32_t* sep;
+    const QpEdge* edges;
+    const void* table;
+    double* partial;
+    int64_t B, nitems;
+    int32_t T, Tp, ldq, Q, C, rows_per_item, G, lpr;
+    uint32_t table_bytes;
+};
+
+template <int KIND, bool TAB_LDS>
+__global__ __launch_bounds__(kV3Threads) void k_cost_v3(V3Args p) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    using E = typename Tab<KIND>::elem;
+    using Acc = typename Tab<KIND>::acc;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    uint32_t tab_off = 0;
+    const E* tab;
+    if constexpr (TAB_LDS) {
+        tab_off = stage_table(smem, p.table, p.table_bytes);
+        tab = reinterpret_cast<const E*>(smem);
+    } else {
+        tab = static_cast<const E*>(p.table);
+    }
+    const int ldq = p.ldq, G = p.G, lpr = p.lpr, C = p.C;
+    uint8_t* strip = smem + tab_off + (size_t)wave * (G + 1) * ldq;  // [row before][G rows]
+    const int nact = G * lpr;
+    const bool lane_on = lane < nact;
+    const int lrow = lane / lpr;
+    const int lq0 = (lane - lrow * lpr) * 16;
+    const int nvalid_row = min(16, max(0, p.Q - lq0));  // qubits of this lane's piece that exist
+
+    for (int64_t it = (int64_t)blockIdx.x * kV3Waves + wave; it < p.nitems; it += (int64_t)gridDim.x * kV3Waves) {
+        const int chunk = (int)(it / p.B);
+        const int64_t b = it - (int64_t)chunk * p.B;
+        const int r0 = chunk * p.rows_per_item;
+        const int r1 = min(p.T, r0 + p.rows_per_item);
+        const uint8_t* base = p.A + (size_t)b * p.Tp * ldq;
+        const int ngroups = (r1 - r0 + G - 1) / G;
+        Acc acc = 0;
+
+        auto fetch = [&](int g) -> uint4 {
+            const int rg = r0 + g * G;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (g < ngroups && lane_on && rg + lrow < r1)
+                v = *reinterpret_cast<const uint4*>(base + (size_t)rg * ldq + lane * 16);
+            return v;
+        };
+
+        if (r0 >= 1 && lane < lpr)
+            *reinterpret_cast<uint4*>(strip + lane * 16) =
+                *reinterpret_cast<const uint4*>(base + (size_t)(r0 - 1) * ldq + lane * 16);
+
+        uint4 ahead[kV3Ahead];
+#pragma unroll
+        for (int k = 0; k < kV3Ahead; ++k) ahead[k] = fetch(k);
+
+        for (int g0 = 0; g0 < ngroups; g0 += kV3Ahead) {
+            uint4 now[kV3Ahead];
+#pragma unroll
+            for (int k = 0; k < kV3Ahead; ++k) now[k] = ahead[k];
+#pragma unroll
+            for (int k = 0; k < kV3Ahead; ++k) ahead[k] = fetch(g0 + kV3Ahead + k);
+#pragma unroll
+            for (int k = 0; k < kV3Ahead; ++k) {
+                const int g = g0 + k;
+                if (g >= ngroups) break;
+                const int rg = r0 + g * G;
+                const uint4 cur = now[k];
+                uint4 prv = make_uint4(0, 0, 0, 0);
+                if (lane_on) {
+                    *reinterpret_cast<uint4*>(strip + ldq + lane * 16) = cur;
+                    prv = *reinterpret_cast<const uint4*>(strip + lane * 16);
+                }
+                // movement: rows 2..T-1, previous row -> this row
+                const int row = rg + lrow;
+                const int nvalid = (lane_on && row >= 2 && row < r1) ? nvalid_row : 0;
+                const uint32_t cw[4] = {cur.x, cur.y, cur.z, cur.w};
+                const uint32_t pw[4] = {prv.x, prv.y, prv.z, prv.w};
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const int nb = min(4, max(0, nvalid - 4 * w));
+                    const uint32_t m = nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u);
+                    const uint32_t c4 = cw[w] & m, p4 = pw[w] & m;
+                    if (__builtin_amdgcn_ballot_w64(c4 != p4) == 0) continue;  // nobody in this column moved
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t pc = (p4 >> (8 * j)) & 0xFFu, cc = (c4 >> (8 * j)) & 0xFFu;
+                        acc += tab[pc * C + cc];
+                    }
+                }
+                // counted two-qubit gates of these slices
+                const int e0 = __builtin_amdgcn_readfirstlane(p.sep[rg]);
+                const int e1 = __builtin_amdgcn_readfirstlane(p.sep[min(rg + G, r1)]);
+                for (int e = e0 + lane; e < e1; e += kWave) {
+                    const QpEdge ed = p.edges[e];
+                    const uint8_t* rowp = strip + ldq + (ed.t - rg) * ldq;
+                    const uint32_t au = rowp[ed.u], av = rowp[ed.v];
+                    acc += tab[au * C + av];
+                }
+                // the last row of the group becomes "the row before" of the next group
+                if (lane_on && lrow == G - 1) *reinterpret_cast<uint4*>(strip + lq0) = cur;
+            }
+        }
+        const double s = wave_sum(acc);
+        if (lane == 0) p.partial[it] = s;
+    }
+}
+
+// Any row pitch: one 256-thread workgroup per item, everything gathered from global memory.
+template <int KIND>
+__global__ __launch_bounds__(256) void k_cost_v3_wide(V3Args p) {
+    using E = typename Tab<KIND>::elem;
+    __shared__ double red[256 / kWave];
+    const E* tab = static_cast<const E*>(p.table);
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    for (int64_t it = blockIdx.x; it < p.nitems; it += gridDim.x) {
+        const int chunk = (int)(it / p.B);
+        const int64_t b = it - (int64_t)chunk * p.B;
+        const int r0 = chunk * p.rows_per_item;
+        const int r1 = min(p.T, r0 + p.rows_per_item);
+        const uint8_t* base = p.A + (size_t)b * p.Tp * p.ldq;
+        double acc = 0.0;
+        for (int row = max(r0, 2); row < r1; ++row) {
+            const uint8_t* cr = base + (size_t)row * p.ldq;
+            const uint8_t* pr = cr - p.ldq;
+            for (int q = threadIdx.x; q < p.Q; q += blockDim.x) acc += (double)tab[(uint32_t)pr[q] * p.C + cr[q]];
+        }
+        for (int e = p.sep[r0] + threadIdx.x; e < p.sep[r1]; e += blockDim.x) {
+            const QpEdge ed = p.edges[e];
+            const uint8_t* cr = base + (size_t)ed.t * p.ldq;
+            acc += (double)tab[(uint32_t)cr[ed.u] * p.C + cr[ed.v]];
+        }
+        acc = wave_sum(acc);
+        __syncthreads();
+        if (lane == 0) red[wave] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double s = 0.0;
+            for (int w = 0; w < 256 / kWave; ++w) s += red[w];
+            p.partial[it] = s;
+        }
+    }
+}
+
+// out[b] = partial[0*B + b] + partial[1*B + b] + ... in chunk order.
+__global__ void k_sum_chunks(const double* partial, int64_t B, int32_t nchunks, double* out) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double s = 0.0;
+    for (int32_t c = 0; c < nchunks; ++c) s += partial[(size_t)c * B + b];
+    out[b] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Cost V1 / V2 / V4: sparse partitions walked visit by visit.
+// ------------------------------------------------------------------------------------------------
+
+struct V2Args {
+    const uint8_t* A;
+    const int32_t* svp;
+    const QpVisit* visits;
+    const void* table;
+    double* partial;
+    int64_t B, nitems;
+    int32_t T, Tp, ldq, C, rows_per_item, mode;
+    uint32_t table_bytes;
+};
+
+template <int KIND, bool TAB_LDS>
+__global__ __launch_bounds__(256) void k_cost_v2(V2Args p) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    using E = typename Tab<KIND>::elem;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int nwaves = blockDim.x / kWave;
+    const E* tab;
+    if constexpr (TAB_LDS) {
+        stage_table(smem, p.table, p.table_bytes);
+        tab = reinterpret_cast<const E*>(smem);
+    } else {
+        tab = static_cast<const E*>(p.table);
+    }
+    const int C = p.C;
+    for (int64_t it = (int64_t)blockIdx.x * nwaves + wave; it < p.nitems; it += (int64_t)gridDim.x * nwaves) {
+        const int chunk = (int)(it / p.B);
+        const int64_t b = it - (int64_t)chunk * p.B;
+        const int r0 = chunk * p.rows_per_item;
+        const int r1 = min(p.T, r0 + p.rows_per_item);
+        const uint8_t* base = p.A + (size_t)b * p.Tp * p.ldq;
+        double acc = 0.0;
+        bool bad = false;
+        for (int i = p.svp[r0] + lane; i < p.svp[r1]; i += kWave) {
+            const QpVisit v = p.visits[i];
+            const uint8_t* rowp = base + (size_t)v.t * p.ldq;
+            const uint32_t cur = rowp[v.q];
+            if (v.partner != 0xFFFFu) {
+                const uint32_t oth = rowp[v.partner];
+                if (cur == QP_ABSENT || oth == QP_ABSENT) {
+                    if (p.mode != QP_V1) bad = true;  // KeyError in the reference
+                } else {
+                    acc += (double)tab[cur * C + oth];
+                }
+            }
+            if (v.prev_t >= 0) {
+                const uint32_t last = base[(size_t)v.prev_t * p.ldq + v.q];
+                if (last != QP_ABSENT && cur != last) {
+                    if (cur == QP_ABSENT) bad = true;  // distance to None: TypeError in the reference
+                    else acc += (double)(p.mode == QP_V4 ? tab[cur * C + last] : tab[last * C + cur]);
+                }
+            }
+        }
+        acc = wave_sum(acc);
+        const bool any_bad = __builtin_amdgcn_ballot_w64(bad) != 0;
+        if (lane == 0) p.partial[it] = any_bad ? std::numeric_limits<double>::infinity() : acc;
+    }
+}
+
+__global__ void k_fill(double* out, int64_t n, double v) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Cost matrices
+// ------------------------------------------------------------------------------------------------
+
+struct CmArgs {
+    const QpEdge* edges;
+    const int16_t* lookahead;
+    const double* D;
+    const int32_t* t;
+    const uint8_t* a;
+    const int32_t* ops;
+    const int32_t* n_ops;
+    const uint8_t* avail;
+    const int32_t* n_avail;
+    double* out;
+    int32_t C, ldq, max_ops, kind;
+};
+
+__device__ inline double pymax(double a, double b) { return b > a ? b : a; }  // Python's max(a, b)
+
+__global__ __launch_bounds__(256) void k_cost_matrix(CmArgs p) {
+    const int64_t b = blockIdx.y;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = idx / p.C, j = idx - i * p.C;
+    if (i >= p.n_ops[b] || j >= p.n_avail[b]) return;
+    const int eid = p.ops[(size_t)b * p.max_ops + i];
+    const QpEdge ed = p.edges[eid];
+    const uint8_t* a = p.a + (size_t)b * p.ldq;
+    const uint32_t c = p.avail[(size_t)b * p.C + j];
+    const uint32_t a1 = a[ed.u], a2 = a[ed.v];
+    double r;
+    if (p.kind == QP_CM_GTRHQA) {
+        // a core whose label is 0 is "falsy" in the reference: leaving core 0 costs nothing
+        double cost = 0.0;
+        if (a1 != 0 && a1 != c) cost += p.D[a1 * p.C + c];
+        if (a2 != 0 && a2 != c) cost += p.D[a2 * p.C + c];
+        r = cost;
+    } else {
+        double att = 0.0;
+        const int16_t* la = p.lookahead + (size_t)eid * 6;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int o = la[k];
+            if (o >= 0) {
+                const double w = k < 2 ? 0.5 : (k < 4 ? 0.25 : 0.125);
+                att += (a[o] == c) ? w * 0.9 : w * 0.3;
+            }
+        }
+        if (p.kind == QP_CM_HQA) {
+            const double m = (double)((a1 != c) + (a2 != c));
+            r = pymax(0.1, pymax(0.1, m - att));
+        } else {
+            double mv = 0.0;
+            if (a1 != c) mv += p.D[a1 * p.C + c];
+            if (a2 != c) mv += p.D[a2 * p.C + c];
+            const double T_ = pymax(0.1, mv - att);
+            double here = 0.0;
+            if (a1 != 0 && a1 != c) here += p.D[a1 * p.C + c];
+            if (a2 != 0 && a2 != c) here += p.D[a2 * p.C + c];
+            const double attraction = here - T_;
+            r = pymax(0.1, here - attraction);
+        }
+    }
+    p.out[((size_t)b * p.max_ops + i) * p.C + j] = r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch helpers
+// ------------------------------------------------------------------------------------------------
+
+int device_cus() {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 256;
+    return n;
+}
+
+int rows_per_item_for(int32_t T, int32_t G) {
+    // about 32 rows per item, a multiple of the group size, so the one extra row read per item is ~3%
+    int r = std::max(G, (32 / G) * G);
+    if (r < kV3Ahead * G && T > kV3Ahead * G) r = kV3Ahead * G;
+    return r;
+}
+
+int check_common(const char* fn, const QpCircuit* circ, const QpDTable* dt, const uint8_t* A, int64_t B,
+                 int32_t Tp, int32_t ldq, const double* out) {
+    if (!circ || !dt || !A || !out) return qp::fail(QP_EINVAL, "%s: null argument", fn);
+    if (B <= 0) return qp::fail(QP_EINVAL, "%s: B must be positive", fn);
+    if (circ->Q <= 0 || circ->T < 0 || circ->Q > 65535) return qp::fail(QP_EINVAL, "%s: bad circuit sizes", fn);
+    if (ldq < circ->Q || ldq % 16 != 0) return qp::fail(QP_EINVAL, "%s: ldq must be >= Q and a multiple of 16", fn);
+    if (dt->C <= 0 || dt->C > 256 || !dt->table) return qp::fail(QP_EINVAL, "%s: bad distance table", fn);
+    if (dt->kind != QP_DT_F64 && dt->kind != QP_DT_U16) return qp::fail(QP_EINVAL, "%s: unknown table kind", fn);
+    if (Tp <= 0) return qp::fail(QP_EINVAL, "%s: Tp must be positive", fn);
+    return QP_OK;
+}
+
+}  // namespace
+
+extern "C" size_t qp_slice_cost_workspace(int32_t T, int64_t B) {
+    if (T <= 0 || B <= 0) return 16;
+    // one double per (chunk, partition); chunks are never shorter than 16 rows unless T is
+    const int64_t max_chunks = (T + 15) / 16 + 1;
+    return (size_t)(max_chunks * B) * sizeof(double);
+}
+
+extern "C" int qp_slice_cost_v3(const QpCircuit* circ, const QpDTable* dt, const uint8_t* A, int64_t B, int32_t Tp,
+                                int32_t ldq, double* out, void* workspace, size_t workspace_bytes, void* stream_) {
+    if (int rc = check_common("qp_slice_cost_v3", circ, dt, A, B, Tp, ldq, out)) return rc;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int32_t T = circ->T;
+    if (Tp < T) return qp::fail(QP_EINVAL, "qp_slice_cost_v3: partition has %d rows, circuit has %d slices", Tp, T);
+    if (T == 0) {
+        k_fill<<<(unsigned)((B + 255) / 256), 256, 0, stream>>>(out, B, 0.0);
+        HIP_TRY(hipGetLastError());
+        return QP_OK;
+    }
+    if (!circ->slice_edge_ptr || (circ->nE > 0 && !circ->edges))
+        return qp::fail(QP_EINVAL, "qp_slice_cost_v3: circuit edge tables missing");
+
+    V3Args p{};
+    p.A = A;
+    p.sep = circ->slice_edge_ptr;
+    p.edges = circ->edges;
+    p.table = dt->table;
+    p.B = B;
+    p.T = T;
+    p.Tp = Tp;
+    p.ldq = ldq;
+    p.Q = circ->Q;
+    p.C = dt->C;
+    const size_t esz = dt->kind == QP_DT_F64 ? 8 : 2;
+    p.table_bytes = (uint32_t)((size_t)dt->C * dt->C * esz);
+    const size_t tab_padded = (p.table_bytes + 15u) & ~(size_t)15;
+    const bool narrow = ldq <= 1024;
+    if (narrow) {
+        p.lpr = ldq / 16;
+        p.G = kWave / p.lpr;
+    } else {
+        p.lpr = 0;
+        p.G = 1;
+    }
+    p.rows_per_item = rows_per_item_for(T, p.G);
+    const int32_t nchunks = (T + p.rows_per_item - 1) / p.rows_per_item;
+    p.nitems = (int64_t)nchunks * B;
+    if (!workspace || workspace_bytes < (size_t)p.nitems * sizeof(double))
+        return qp::fail(QP_ENOSPC, "qp_slice_cost_v3: workspace needs %zu bytes", (size_t)p.nitems * sizeof(double));
+    p.partial = static_cast<double*>(workspace);
+    const int cus = device_cus();
+
+    if (narrow) {
+        const size_t strips = (size_t)kV3Waves * (p.G + 1) * ldq;
+        const bool tab_lds = tab_padded + strips <= (size_t)kLdsBytes;
+        const size_t lds = strips + (tab_lds ? tab_padded : 0);
+        const unsigned grid = (unsigned)std::min<int64_t>(cus, (p.nitems + kV3Waves - 1) / kV3Waves);
+        void (*kern)(V3Args) = nullptr;
+        if (dt->kind == QP_DT_F64) kern = tab_lds ? k_cost_v3<QP_DT_F64, true> : k_cost_v3<QP_DT_F64, false>;
+        else kern = tab_lds ? k_cost_v3<QP_DT_U16, true> : k_cost_v3<QP_DT_U16, false>;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        kern<<<grid, kV3Threads, lds, stream>>>(p);
+    } else {
+        const unsigned grid = (unsigned)std::min<int64_t>((int64_t)cus * 8, p.nitems);
+        if (dt->kind == QP_DT_F64) k_cost_v3_wide<QP_DT_F64><<<grid, 256, 0, stream>>>(p);
+        else k_cost_v3_wide<QP_DT_U16><<<grid, 256, 0, stream>>>(p);
+    }
+    HIP_TRY(hipGetLastError());
+    k_sum_chunks<<<(unsigned)((B + 255) / 256), 256, 0, stream>>>(p.partial, B, nchunks, out);
+    HIP_TRY(hipGetLastError());
+    return QP_OK;
+}
+
+extern "C" int qp_slice_cost_v2(const QpCircuit* circ, const QpDTable* dt, const uint8_t* A, int64_t B, int32_t Tp,
+                                int32_t ldq, int32_t flags, double* out, void* workspace, size_t workspace_bytes,
+                                void* stream_) {
+    if (int rc = check_common("qp_slice_cost_v2", circ, dt, A, B, Tp, ldq, out)) return rc;
+    if (flags != QP_V1 && flags != QP_V2 && flags != QP_V4) return qp::fail(QP_EINVAL, "qp_slice_cost_v2: bad flags");
+    if (dt->C > 255) return qp::fail(QP_EINVAL, "qp_slice_cost_v2: at most 255 cores (0xFF marks an absent qubit)");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    int32_t T = circ->T;
+    if (Tp < T) {
+        if (flags == QP_V1) {
+            T = Tp;  // Placer.py:87-88
+        } else {      // partition[i] past the end: IndexError in the reference, inf in its results
+            k_fill<<<(unsigned)((B + 255) / 256), 256, 0, stream>>>(out, B, std::numeric_limits<double>::infinity());
+            HIP_TRY(hipGetLastError());
+            return QP_OK;
+        }
+    }
+    if (T == 0 || circ->nV == 0) {
+        k_fill<<<(unsigned)((B + 255) / 256), 256, 0, stream>>>(out, B, 0.0);
+        HIP_TRY(hipGetLastError());
+        return QP_OK;
+    }
+    if (!circ->slice_visit_ptr || !circ->visits) return qp::fail(QP_EINVAL, "qp_slice_cost_v2: circuit visit tables missing");
+    V2Args p{};
+    p.A = A;
+    p.svp = circ->slice_visit_ptr;
+    p.visits = circ->visits;
+    p.table = dt->table;
+    p.B = B;
+    p.T = T;
+    p.Tp = Tp;
+    p.ldq = ldq;
+    p.C = dt->C;
+    p.mode = flags;
+    p.rows_per_item = 32;
+    const int32_t nchunks = (T + p.rows_per_item - 1) / p.rows_per_item;
+    p.nitems = (int64_t)nchunks * B;
+    if (!workspace || workspace_bytes < (size_t)p.nitems * sizeof(double))
+        return qp::fail(QP_ENOSPC, "qp_slice_cost_v2: workspace needs %zu bytes", (size_t)p.nitems * sizeof(double));
+    p.partial = static_cast<double*>(workspace);
+    const size_t esz = dt->kind == QP_DT_F64 ? 8 : 2;
+    p.table_bytes = (uint32_t)((size_t)dt->C * dt->C * esz);
+    const size_t tab_padded = (p.table_bytes + 15u) & ~(size_t)15;
+    const bool tab_lds = tab_padded <= 64 * 1024;
+    const size_t lds = tab_lds ? tab_padded : 0;
+    const int cus = device_cus();
+    const unsigned grid = (unsigned)std::min<int64_t>((int64_t)cus * 2, (p.nitems + 3) / 4);
+    void (*kern)(V2Args) = nullptr;
+    if (dt->kind == QP_DT_F64) kern = tab_lds ? k_cost_v2<QP_DT_F64, true> : k_cost_v2<QP_DT_F64, false>;
+    else kern = tab_lds ? k_cost_v2<QP_DT_U16, true> : k_cost_v2<QP_DT_U16, false>;
+    kern<<<grid, 256, lds, stream>>>(p);
+    HIP_TRY(hipGetLastError());
+    k_sum_chunks<<<(unsigned)((B + 255) / 256), 256, 0, stream>>>(p.partial, B, nchunks, out);
+    HIP_TRY(hipGetLastError());
+    return QP_OK;
+}
+
+extern "C" int qp_cost_matrix(int32_t kind, const QpCircuit* circ, const QpDTable* dt, int64_t B, const int32_t* t,
+                              const uint8_t* a, int32_t ldq, const int32_t* ops, const int32_t* n_ops, int32_t max_ops,
+                              const uint8_t* avail, const int32_t* n_avail, double* cost_out, void* stream_) {
+    if (kind != QP_CM_HQA && kind != QP_CM_TRHQA && kind != QP_CM_GTRHQA) return qp::fail(QP_EINVAL, "qp_cost_matrix: bad kind");
+    if (!circ || !dt || !a || !ops || !n_ops || !avail || !n_avail || !cost_out)
+        return qp::fail(QP_EINVAL, "qp_cost_matrix: null argument");
+    if (B <= 0 || B > 65535) return qp::fail(QP_EINVAL, "qp_cost_matrix: B must be 1..65535 per call");
+    if (max_ops <= 0) return qp::fail(QP_EINVAL, "qp_cost_matrix: max_ops must be positive");
+    if (dt->kind != QP_DT_F64 || !dt->table) return qp::fail(QP_EINVAL, "qp_cost_matrix: needs a QP_DT_F64 distance table");
+    if (dt->C <= 0 || dt->C > 256) return qp::fail(QP_EINVAL, "qp_cost_matrix: bad core count");
+    if (!circ->edges || (kind != QP_CM_GTRHQA && !circ->lookahead)) return qp::fail(QP_EINVAL, "qp_cost_matrix: circuit tables missing");
+    if (ldq < circ->Q) return qp::fail(QP_EINVAL, "qp_cost_matrix: ldq < Q");
+    (void)t;
+    CmArgs p{};
+    p.edges = circ->edges;
+    p.lookahead = circ->lookahead;
+    p.D = static_cast<const double*>(dt->table);
+    p.t = t;
+    p.a = a;
+    p.ops = ops;
+    p.n_ops = n_ops;
+    p.avail = avail;
+    p.n_avail = n_avail;
+    p.out = cost_out;
+    p.C = dt->C;
+    p.ldq = ldq;
+    p.max_ops = max_ops;
+    p.kind = kind;
+    const dim3 grid((unsigned)(((int64_t)max_ops * dt->C + 255) / 256), (unsigned)B);
+    k_cost_matrix<<<grid, 256, 0, static_cast<hipStream_t>(stream_)>>>(p);
+    HIP_TRY(hipGetLastError());
+    return QP_OK;
+}

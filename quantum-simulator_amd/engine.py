@@ -1,0 +1,234 @@
+"""Device-side state and launches: circuit tables and distance tables in HBM, and thin wrappers that
+hand torch-owned device buffers to the C ABI (include/qplace.h).  torch is used for device memory,
+streams and copies only; every number comes out of libqplace.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import (QP_ABSENT, QP_CM_GTRHQA, QP_CM_HQA, QP_CM_TRHQA, QP_DT_F64, QP_DT_U16, QP_V1, QP_V2, QP_V4,
+                   QpCircuit, QpDTable, check, lib, ptr)
+from .timeslices import CircuitIR
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def default_device():
+    torch = _torch()
+    if not torch.cuda.is_available():
+        raise RuntimeError("no GPU visible: the cost kernels run on an MI355X only (there is no CPU path)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _stream_ptr(device):
+    return C.c_void_p(_torch().cuda.current_stream(device).cuda_stream)
+
+
+def _to_dev(arr: np.ndarray, device):
+    torch = _torch()
+    flat = np.ascontiguousarray(arr).view(np.uint8).reshape(-1)
+    if flat.size == 0:
+        return torch.zeros(16, dtype=torch.uint8, device=device)
+    return torch.from_numpy(flat.copy()).to(device)
+
+
+# ------------------------------------------------------------------------------------------------
+# host-only entry points
+# ------------------------------------------------------------------------------------------------
+
+def apsp(C_: int, eu, ev, w) -> np.ndarray:
+    """All-pairs weighted core distances (row = source), via qp_apsp_f64."""
+    eu = np.ascontiguousarray(eu, np.int32)
+    ev = np.ascontiguousarray(ev, np.int32)
+    w = np.ascontiguousarray(w, np.float64)
+    D = np.empty((C_, C_), np.float64)
+    check(lib().qp_apsp_f64(C_, len(eu), ptr(eu), ptr(ev), ptr(w), ptr(D)))
+    return D
+
+
+def hops(C_: int, eu, ev) -> np.ndarray:
+    eu = np.ascontiguousarray(eu, np.int32)
+    ev = np.ascontiguousarray(ev, np.int32)
+    H = np.empty((C_, C_), np.float64)
+    check(lib().qp_hops_f64(C_, len(eu), ptr(eu), ptr(ev), ptr(H)))
+    return H
+
+
+def lsap(cost: np.ndarray):
+    """Row/column indices of the optimal assignment, tie-for-tie what scipy returns."""
+    cost = np.ascontiguousarray(cost, np.float64)
+    nr, nc = cost.shape
+    k = min(nr, nc)
+    rows = np.empty(k, np.int32)
+    cols = np.empty(k, np.int32)
+    rc = lib().qp_lsap_f64(nr, nc, ptr(cost), ptr(rows), ptr(cols))
+    if rc == _lib.QP_OK:
+        return rows, cols
+    raise ValueError(lib().qp_last_error().decode())
+
+
+def lsap_batch(costs: np.ndarray, nr: np.ndarray, nc: np.ndarray, threads: int = 8):
+    """costs [n, R, L] (problem k uses the top-left nr[k] x nc[k]); returns rows, cols [n, min(R, L)], status."""
+    costs = np.ascontiguousarray(costs, np.float64)
+    n, R, L = costs.shape
+    nr = np.ascontiguousarray(nr, np.int32)
+    nc = np.ascontiguousarray(nc, np.int32)
+    k = max(1, min(R, L))
+    rows = np.full((n, k), -1, np.int32)
+    cols = np.full((n, k), -1, np.int32)
+    status = np.zeros(n, np.int32)
+    check(lib().qp_lsap_f64_batch(n, ptr(nr), ptr(nc), ptr(costs), R * L, L, ptr(rows), ptr(cols), k, ptr(status),
+                                  threads))
+    return rows, cols, status
+
+
+# ------------------------------------------------------------------------------------------------
+# device-resident tables
+# ------------------------------------------------------------------------------------------------
+
+class DeviceCircuit:
+    """A CircuitIR uploaded once; ``.c`` is the QpCircuit the ABI takes."""
+
+    def __init__(self, ir: CircuitIR, device=None):
+        self.ir = ir
+        self.device = device if device is not None else default_device()
+        if ir.Q > 32767:
+            raise ValueError("at most 32767 qubits")
+        self._sep = _to_dev(ir.slice_edge_ptr, self.device)
+        self._edges = _to_dev(ir.edge_records, self.device)
+        self._la = _to_dev(ir.lookahead, self.device)
+        self._svp = _to_dev(ir.slice_visit_ptr, self.device)
+        self._visits = _to_dev(ir.visit_records, self.device)
+        self.c = QpCircuit(ir.Q, ir.T, ir.nE, ir.nV, self._sep.data_ptr(), self._edges.data_ptr(),
+                           self._la.data_ptr(), self._svp.data_ptr(), self._visits.data_ptr())
+        self.ldq = (ir.Q + 15) // 16 * 16
+
+    @property
+    def csr_bytes(self):
+        return 4 * (self.ir.T + 1) + 8 * self.ir.nE
+
+
+class DistanceTable:
+    """A C x C distance matrix on the host (``D``) and on the device in two forms: fp64 (cost
+    matrices) and the packed form qp_dtable_pack chooses (uint16 when every entry is an integer)."""
+
+    def __init__(self, D: np.ndarray, device=None):
+        torch = _torch()
+        self.device = device if device is not None else default_device()
+        self.D = np.ascontiguousarray(D, np.float64)
+        self.C = int(self.D.shape[0])
+        n = self.C * self.C
+        staging = np.zeros((n * 8 + 15) // 16 * 16, np.uint8)
+        kind = C.c_int32(0)
+        nbytes = C.c_size_t(0)
+        check(lib().qp_dtable_pack(ptr(self.D), self.C, ptr(staging), staging.size, C.byref(kind), C.byref(nbytes)))
+        self.kind = kind.value
+        padded = (nbytes.value + 15) // 16 * 16
+        self._packed = torch.from_numpy(staging[:padded].copy()).to(self.device)
+        self.packed = QpDTable(self.kind, self.C, self._packed.data_ptr())
+        if self.kind == QP_DT_F64:
+            self._f64 = self._packed
+        else:
+            Dz = self.D.copy()
+            np.fill_diagonal(Dz, 0.0)
+            buf = np.zeros((n * 8 + 15) // 16 * 16, np.uint8)
+            buf[:n * 8] = Dz.view(np.uint8).reshape(-1)
+            self._f64 = torch.from_numpy(buf).to(self.device)
+        self.f64 = QpDTable(QP_DT_F64, self.C, self._f64.data_ptr())
+
+    @classmethod
+    def from_network(cls, network, device=None, weighted=True):
+        from .multicore import graph_tables
+        nodes, eu, ev, w = graph_tables(network)
+        D = apsp(len(nodes), eu, ev, w) if weighted else hops(len(nodes), eu, ev)
+        t = cls(D, device)
+        t.nodes = nodes
+        return t
+
+
+# ------------------------------------------------------------------------------------------------
+# launches
+# ------------------------------------------------------------------------------------------------
+
+class Engine:
+    """Launches on one device.  Holds a growable workspace so repeated calls allocate nothing."""
+
+    def __init__(self, device=None):
+        self.device = device if device is not None else default_device()
+        self._ws = None
+
+    def _workspace(self, nbytes):
+        torch = _torch()
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def _check_partitions(self, dc: DeviceCircuit, A):
+        torch = _torch()
+        if A.dtype != torch.uint8 or A.dim() != 3 or not A.is_contiguous() or A.device != self.device:
+            raise ValueError("A must be a contiguous uint8 [B, Tp, ldq] tensor on the engine's device")
+        B, Tp, ldq = A.shape
+        if ldq % 16 or ldq < dc.ir.Q:
+            raise ValueError("row pitch must be a multiple of 16 and >= Q")
+        return B, Tp, ldq
+
+    def cost_v3(self, dc: DeviceCircuit, dt: DistanceTable, A, out=None, table="packed"):
+        """HQA-family cost of B dense partitions; A is uint8 [B, Tp, ldq] on the device."""
+        torch = _torch()
+        B, Tp, ldq = self._check_partitions(dc, A)
+        if out is None:
+            out = torch.empty(B, dtype=torch.float64, device=self.device)
+        ws = self._workspace(lib().qp_slice_cost_workspace(dc.ir.T, B))
+        tab = dt.packed if table == "packed" else dt.f64
+        check(lib().qp_slice_cost_v3(C.byref(dc.c), C.byref(tab), A.data_ptr(), B, Tp, ldq, out.data_ptr(),
+                                     ws.data_ptr(), ws.numel(), _stream_ptr(self.device)))
+        return out
+
+    def cost_v2(self, dc: DeviceCircuit, dt: DistanceTable, A, variant=QP_V2, out=None, table="packed"):
+        """Gate-ordered cost (V1/V2/V4) of B sparse partitions (0xFF = absent)."""
+        torch = _torch()
+        B, Tp, ldq = self._check_partitions(dc, A)
+        if out is None:
+            out = torch.empty(B, dtype=torch.float64, device=self.device)
+        ws = self._workspace(lib().qp_slice_cost_workspace(dc.ir.T, B))
+        tab = dt.packed if table == "packed" else dt.f64
+        check(lib().qp_slice_cost_v2(C.byref(dc.c), C.byref(tab), A.data_ptr(), B, Tp, ldq, variant,
+                                     out.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(self.device)))
+        return out
+
+    def cost_matrix(self, kind, dc: DeviceCircuit, dt: DistanceTable, t, a, ops, n_ops, avail, n_avail, out=None):
+        """Batched op x core matrices; all arguments are device tensors (see qp_cost_matrix)."""
+        torch = _torch()
+        B, max_ops = ops.shape
+        if out is None:
+            out = torch.empty((B, max_ops, dt.C), dtype=torch.float64, device=self.device)
+        check(lib().qp_cost_matrix(kind, C.byref(dc.c), C.byref(dt.f64), B, t.data_ptr(), a.data_ptr(), a.shape[1],
+                                   ops.data_ptr(), n_ops.data_ptr(), max_ops, avail.data_ptr(), n_avail.data_ptr(),
+                                   out.data_ptr(), _stream_ptr(self.device)))
+        return out
+
+
+def rows_to_array(rows, Q, ldq=None, absent=QP_ABSENT) -> np.ndarray:
+    """List of rows (core index or None per qubit) -> uint8 [Tp, ldq]."""
+    ldq = ldq if ldq is not None else (Q + 15) // 16 * 16
+    out = np.zeros((len(rows), ldq), np.uint8)
+    for t, r in enumerate(rows):
+        out[t, :Q] = [absent if c is None else c for c in r]
+    return out
+
+
+_engines = {}
+
+
+def get_engine(device=None) -> Engine:
+    device = device if device is not None else default_device()
+    key = str(device)
+    if key not in _engines:
+        _engines[key] = Engine(device)
+    return _engines[key]

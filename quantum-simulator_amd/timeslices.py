@@ -1,0 +1,207 @@
+"""Timeslicing and the integer tables the kernels consume.
+
+``slice_gate_indices`` is the reference's ASAP layering (BasePlacer.break_into_timeslices,
+Placer.py:14-61) on gate indices.  It keeps the reference's data structures where they decide the
+result: the successor collections are Python sets (their iteration order fixes the order of the next
+ready list, hence the order of commands inside later slices, hence the row order of every cost
+matrix), and a successor of two gates of one slice is queued twice and dropped by the busy test.
+
+``CircuitIR`` flattens a circuit into numpy tables:
+  edges      counted two-qubit gates (two qubits, not Measure/Reset; HQA_placer.py:66-67), slice order
+  lookahead  per edge, the other qubit of the two-qubit commands touching it in the next three slices
+             (HQA_placer.py:227-237); depends on the circuit only
+  visits     the (slice, gate, qubit) walk of the gate-ordered cost functions (BFS_placer.py:214-237)
+             with, per visit, the previous slice in which the qubit was visited
+"""
+from __future__ import annotations
+
+import weakref
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+from .circuit import OpType
+
+
+def slice_gate_indices(gate_q: Sequence[Tuple[int, ...]]) -> List[List[int]]:
+    n = len(gate_q)
+    pred = [set() for _ in range(n)]
+    succ = [set() for _ in range(n)]
+    latest = {}
+    for g, qs in enumerate(gate_q):
+        for q in qs:
+            p = latest.get(q)
+            if p is not None:
+                pred[g].add(p)
+                succ[p].add(g)
+            latest[q] = g
+    ready = [g for g in range(n) if not pred[g]]
+    placed = set()
+    slices = []
+    while ready:
+        layer, busy = [], set()
+        for g in ready:
+            qs = gate_q[g]
+            if busy.isdisjoint(qs):
+                layer.append(g)
+                busy.update(qs)
+                placed.add(g)
+        upcoming = []
+        for g in layer:
+            for s in succ[g]:
+                if s not in placed and pred[s] <= placed:
+                    upcoming.append(s)
+        slices.append(layer)
+        ready = upcoming
+    return slices
+
+
+class CircuitIR:
+    """Integer view of one circuit.  Build with ``CircuitIR.from_circuit`` or ``from_gate_tables``."""
+
+    def __init__(self, Q: int, gate_q, gate_mr, slices=None, qubits=None, commands=None):
+        self.Q = int(Q)
+        self.gate_q = [tuple(int(x) for x in g) for g in gate_q]
+        self.gate_mr = [bool(x) for x in gate_mr]
+        self.slices = slices if slices is not None else slice_gate_indices(self.gate_q)
+        self.T = len(self.slices)
+        self.qubits = qubits          # circuit.qubits order (objects), or None
+        self.commands = commands      # command objects in file order, or None
+        self._build_edges()
+        self._build_lookahead()
+        self._build_visits()
+
+    # -- construction ---------------------------------------------------------------------------
+    @classmethod
+    def from_circuit(cls, circuit) -> "CircuitIR":
+        qubits = list(circuit.qubits)
+        index = {q: i for i, q in enumerate(qubits)}
+        commands = list(circuit)
+        gate_q = [tuple(index[q] for q in c.qubits) for c in commands]
+        gate_mr = [c.op.type in (OpType.Measure, OpType.Reset) or getattr(c.op.type, "name", "") in ("Measure", "Reset")
+                   for c in commands]
+        return cls(len(qubits), gate_q, gate_mr, qubits=qubits, commands=commands)
+
+    @classmethod
+    def from_gate_tables(cls, Q, q0, q1, mr=None, slices=None) -> "CircuitIR":
+        gate_q = [(int(a),) if b < 0 else (int(a), int(b)) for a, b in zip(q0, q1)]
+        return cls(Q, gate_q, mr if mr is not None else [False] * len(gate_q), slices=slices)
+
+    def _build_edges(self):
+        eu, ev, et, ptr = [], [], [], [0]
+        self.edge_of_gate = {}
+        for t, layer in enumerate(self.slices):
+            for g in layer:
+                qs = self.gate_q[g]
+                if len(qs) == 2 and not self.gate_mr[g]:
+                    self.edge_of_gate[g] = len(eu)
+                    eu.append(qs[0])
+                    ev.append(qs[1])
+                    et.append(t)
+            ptr.append(len(eu))
+        self.nE = len(eu)
+        self.edge_u = np.asarray(eu, np.uint16)
+        self.edge_v = np.asarray(ev, np.uint16)
+        self.edge_t = np.asarray(et, np.int32)
+        self.slice_edge_ptr = np.asarray(ptr, np.int32)
+        rec = np.zeros(self.nE, dtype=np.dtype([("u", "<u2"), ("v", "<u2"), ("t", "<i4")]))
+        rec["u"], rec["v"], rec["t"] = self.edge_u, self.edge_v, self.edge_t
+        self.edge_records = rec
+
+    def _build_lookahead(self):
+        T, Q, nE = self.T, self.Q, self.nE
+        la = np.full((nE, 6), -1, np.int16)
+        if nE and T > 1:
+            # position and operands of the two-qubit command holding each qubit, per slice
+            pos = np.full((T, Q), -1, np.int32)
+            first = np.zeros((T, Q), np.int32)
+            second = np.zeros((T, Q), np.int32)
+            for t, layer in enumerate(self.slices):
+                for k, g in enumerate(layer):
+                    qs = self.gate_q[g]
+                    if len(qs) == 2:
+                        for q in qs:
+                            pos[t, q] = k
+                            first[t, q] = qs[0]
+                            second[t, q] = qs[1]
+            u = self.edge_u.astype(np.int64)
+            v = self.edge_v.astype(np.int64)
+            for dt in (1, 2, 3):
+                tt = self.edge_t.astype(np.int64) + dt
+                ok = tt < T
+                tc = np.where(ok, tt, 0)
+                cand = []
+                for x in (u, v):
+                    p = np.where(ok, pos[tc, x], -1)
+                    f1, f2 = first[tc, x], second[tc, x]
+                    other = np.where((f1 == u) | (f1 == v), f2, f1)
+                    cand.append((p, other))
+                (pu, ou), (pv, ov) = cand
+                pv = np.where(pv == pu, -1, pv)  # both qubits in one command: one term
+                swap = (pu < 0) | ((pv >= 0) & (pv < pu))
+                p1 = np.where(swap, pv, pu)
+                o1 = np.where(swap, ov, ou)
+                p2 = np.where(swap, pu, pv)
+                o2 = np.where(swap, ou, ov)
+                la[:, 2 * (dt - 1)] = np.where(p1 >= 0, o1, -1)
+                la[:, 2 * (dt - 1) + 1] = np.where(p2 >= 0, o2, -1)
+        self.lookahead = la
+
+    def _build_visits(self):
+        vq, vp, vt, vprev, ptr = [], [], [], [], [0]
+        seen_at = {}
+        for t, layer in enumerate(self.slices):
+            for g in layer:
+                qs = self.gate_q[g]
+                counted = len(qs) == 2 and not self.gate_mr[g]
+                for k, q in enumerate(qs):
+                    vq.append(q)
+                    vp.append(qs[1] if (counted and k == 0) else 0xFFFF)
+                    vt.append(t)
+                    vprev.append(seen_at.get(q, -1))
+                for q in qs:
+                    seen_at[q] = t
+            ptr.append(len(vq))
+        self.nV = len(vq)
+        rec = np.zeros(self.nV, dtype=np.dtype([("q", "<u2"), ("partner", "<u2"), ("t", "<i4"), ("prev_t", "<i4"),
+                                                ("pad", "<i4")]))
+        rec["q"], rec["partner"], rec["t"], rec["prev_t"] = vq, vp, vt, vprev
+        self.visit_records = rec
+        self.slice_visit_ptr = np.asarray(ptr, np.int32)
+
+    # -- helpers ----------------------------------------------------------------------------------
+    def slice_ops(self, t: int):
+        """(edge index, u, v) of the counted gates of slice t, slice order."""
+        a, b = int(self.slice_edge_ptr[t]), int(self.slice_edge_ptr[t + 1])
+        return [(e, int(self.edge_u[e]), int(self.edge_v[e])) for e in range(a, b)]
+
+    def active_qubits(self, t: int):
+        a, b = int(self.slice_visit_ptr[t]), int(self.slice_visit_ptr[t + 1])
+        return self.visit_records["q"][a:b]
+
+    def command_slices(self):
+        """Timeslices as lists of command objects (the reference's return type)."""
+        if self.commands is None:
+            raise ValueError("this IR was not built from a circuit object")
+        return [[self.commands[g] for g in layer] for layer in self.slices]
+
+
+_ir_cache = weakref.WeakKeyDictionary()
+
+
+def circuit_ir(circuit) -> CircuitIR:
+    """IR of a circuit object, cached per object (the reference re-slices the circuit in every
+    place and cost call, HQA_placer.py:28,264)."""
+    try:
+        hit = _ir_cache.get(circuit)
+    except TypeError:
+        hit = None
+    n = sum(1 for _ in circuit)
+    if hit is not None and hit[0] == n:
+        return hit[1]
+    ir = CircuitIR.from_circuit(circuit)
+    try:
+        _ir_cache[circuit] = (n, ir)
+    except TypeError:
+        pass
+    return ir

@@ -1,0 +1,230 @@
+"""GPU parity tests: the HIP kernels, called through the C ABI, against the CPU oracle and the
+reference-generated fixtures.  Integer distance tables must agree exactly; fp64 tables within 1e-12
+relative (the sums are formed in a different order from the reference's sequential loop)."""
+import numpy as np
+import pytest
+
+from conftest import ALL_CASES, SMALL_CASES, load_case
+from oracle import placer_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-12
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    from quantum_simulator_amd import engine
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need an MI355X; none is visible")
+    dev = torch.device("cuda", 0)
+    return torch, engine, engine.Engine(dev), dev
+
+
+def _close(got, want, exact):
+    if np.isinf(want):
+        return np.isinf(got)
+    if exact:
+        return got == want
+    return abs(got - want) <= RTOL * max(1.0, abs(want))
+
+
+def _pad(arr, ldq):
+    out = np.zeros(arr.shape[:-1] + (ldq,), np.uint8)
+    out[..., :arr.shape[-1]] = arr
+    return out
+
+
+@pytest.mark.parametrize("name", ALL_CASES)
+def test_cost_v3_golden(gpu, name):
+    torch, engine, eng, dev = gpu
+    gc = load_case(name)
+    from quantum_simulator_amd.timeslices import CircuitIR
+    ir = CircuitIR(gc.Q, gc.gate_q, gc.gate_mr, slices=gc.slices)
+    dc = engine.DeviceCircuit(ir, dev)
+    dt = engine.DistanceTable(gc.D, dev)
+    exact = name.endswith("_i")
+    assert (dt.kind == engine.QP_DT_U16) == exact
+    for p in ("HQA", "TRHQA", "GTRHQA"):
+        if not gc.has(p):
+            continue
+        A = torch.from_numpy(_pad(gc.part(p), dc.ldq)[None].copy()).to(dev)
+        for table in ("packed", "f64"):
+            got = float(eng.cost_v3(dc, dt, A, table=table).cpu()[0])
+            assert _close(got, gc.cost(p), exact), (p, table, got, gc.cost(p))
+    # the three partitions of equal length as one batch, plus a repeat for run-to-run determinism
+    parts = [gc.part(p) for p in ("HQA", "TRHQA") if gc.has(p)]
+    if parts:
+        A = torch.from_numpy(np.stack([_pad(x, dc.ldq) for x in parts] * 3)).to(dev)
+        r1 = eng.cost_v3(dc, dt, A).cpu().numpy()
+        r2 = eng.cost_v3(dc, dt, A).cpu().numpy()
+        assert r1.tobytes() == r2.tobytes()
+        assert r1[0] == r1[len(parts)] == r1[2 * len(parts)]
+
+
+@pytest.mark.parametrize("name", ALL_CASES)
+def test_cost_v2_v1_v4_golden(gpu, name):
+    torch, engine, eng, dev = gpu
+    gc = load_case(name)
+    from quantum_simulator_amd.timeslices import CircuitIR
+    ir = CircuitIR(gc.Q, gc.gate_q, gc.gate_mr, slices=gc.slices)
+    dc = engine.DeviceCircuit(ir, dev)
+    dt = engine.DistanceTable(gc.D, dev)
+    ht = engine.DistanceTable(gc.hops.astype(np.float64), dev)
+    exact = name.endswith("_i")
+    for p in ("BFS", "RANDOM"):
+        A = torch.from_numpy(_pad(gc.part(p), dc.ldq)[None].copy()).to(dev)
+        got = float(eng.cost_v2(dc, dt, A, engine.QP_V2).cpu()[0])
+        assert _close(got, gc.cost(p), exact), (p, got, gc.cost(p))
+        got = float(eng.cost_v2(dc, dt, A, engine.QP_V1).cpu()[0])
+        assert _close(got, gc.cost_v1(p), exact), (p, "v1", got, gc.cost_v1(p))
+        try:
+            want = O.cost_v4(gc.slices, gc.gate_q, gc.gate_mr, gc.part_rows(p), gc.hops.tolist())
+        except O.CostError:
+            want = float("inf")
+        got = float(eng.cost_v2(dc, ht, A, engine.QP_V4).cpu()[0])
+        assert got == want, (p, "v4", got, want)
+    for p in ("HQA", "GTRHQA"):
+        if gc.has(p):
+            A = torch.from_numpy(_pad(gc.part(p), dc.ldq)[None].copy()).to(dev)
+            got = float(eng.cost_v2(dc, dt, A, engine.QP_V1).cpu()[0])
+            assert _close(got, gc.cost_v1(p), exact), (p, "v1 dense", got)
+
+
+SHAPES = [  # Q, T, C, B, integer weights
+    (5, 9, 4, 3, False), (17, 40, 16, 5, True), (63, 70, 64, 4, False), (64, 33, 64, 7, True),
+    (100, 21, 100, 3, False), (130, 50, 128, 2, False), (500, 12, 200, 2, True), (1024, 37, 256, 3, True),
+    (1024, 6, 256, 2, False), (1000, 5, 16, 2, False), (1500, 7, 64, 2, False), (33, 1, 8, 2, False),
+    (33, 2, 8, 2, True), (48, 3, 8, 2, False),
+]
+
+
+def _random_setup(Q, T, C, integer, seed):
+    from quantum_simulator_amd import layered_gate_arrays
+    from quantum_simulator_amd.timeslices import CircuitIR
+    rng = np.random.default_rng(seed)
+    q0, q1, _ = layered_gate_arrays(Q, T, 0.5, seed=seed)
+    # drop a random third of the gates so slices are ragged (some qubits idle, some slices short)
+    keep = rng.random(len(q0)) > 0.33
+    ir = CircuitIR.from_gate_tables(Q, q0[keep], q1[keep])
+    # ring + chords, random weights
+    eu = list(range(C)) + [int(x) for x in rng.integers(0, C, size=C // 2)]
+    ev = [(i + 1) % C for i in range(C)] + [int(x) for x in rng.integers(0, C, size=C // 2)]
+    ok = [k for k in range(len(eu)) if eu[k] != ev[k]]
+    eu, ev = [eu[k] for k in ok], [ev[k] for k in ok]
+    w = rng.integers(1, 6, size=len(eu)).astype(float) if integer else rng.uniform(1, 3, size=len(eu))
+    return ir, eu, ev, w, rng
+
+
+@pytest.mark.parametrize("Q,T,C,B,integer", SHAPES)
+def test_cost_v3_random(gpu, Q, T, C, B, integer):
+    torch, engine, eng, dev = gpu
+    ir, eu, ev, w, rng = _random_setup(Q, T, C, integer, seed=Q * 7 + T)
+    D = engine.apsp(C, eu, ev, w)
+    dc, dt = engine.DeviceCircuit(ir, dev), engine.DistanceTable(D, dev)
+    assert (dt.kind == engine.QP_DT_U16) == integer
+    Tp = ir.T + (1 if Q % 2 else 0)
+    A = rng.integers(0, C, size=(B, Tp, dc.ldq), dtype=np.uint8)
+    A[:, :, Q:] = rng.integers(0, 256, size=(B, Tp, dc.ldq - Q), dtype=np.uint8)  # pad bytes are garbage
+    A[0, 1:] = A[0, :1]  # one partition that never moves
+    got = eng.cost_v3(dc, dt, torch.from_numpy(A).to(dev)).cpu().numpy()
+    Dl = D.tolist()
+    for b in range(B):
+        want = O.cost_v3(ir.slices, ir.gate_q, ir.gate_mr, A[b, :, :Q].tolist(), Dl)
+        assert _close(got[b], want, integer), (b, got[b], want)
+
+
+@pytest.mark.parametrize("Q,T,C,B,integer", [s for s in SHAPES if s[2] <= 255][:10])
+def test_cost_v2_random(gpu, Q, T, C, B, integer):
+    torch, engine, eng, dev = gpu
+    ir, eu, ev, w, rng = _random_setup(Q, T, C, integer, seed=Q * 11 + T)
+    D = engine.apsp(C, eu, ev, w)
+    H = engine.hops(C, eu, ev)
+    dc, dt, ht = engine.DeviceCircuit(ir, dev), engine.DistanceTable(D, dev), engine.DistanceTable(H, dev)
+    A = np.full((B, ir.T, dc.ldq), 0xFF, np.uint8)
+    for b in range(B):
+        for t in range(ir.T):
+            act = ir.active_qubits(t)
+            A[b, t, act] = rng.integers(0, C, size=len(act))
+    # instance 1: drop one active qubit somewhere (an error in V2, maybe not in V1)
+    if B > 1 and ir.nV:
+        v = ir.visit_records[int(rng.integers(0, ir.nV))]
+        A[1, v["t"], v["q"]] = 0xFF
+    Ad = torch.from_numpy(A).to(dev)
+    Dl, Hl = D.tolist(), H.tolist()
+    for variant, fn, tab, tabl in ((engine.QP_V2, O.cost_v2, dt, Dl), (engine.QP_V1, O.cost_v1, dt, Dl),
+                                   (engine.QP_V4, O.cost_v4, ht, Hl)):
+        got = eng.cost_v2(dc, tab, Ad, variant).cpu().numpy()
+        for b in range(B):
+            rows = [[None if c == 0xFF else int(c) for c in r[:Q]] for r in A[b]]
+            try:
+                want = float(fn(ir.slices, ir.gate_q, ir.gate_mr, rows, tabl))
+            except O.CostError:
+                want = float("inf")
+            assert _close(got[b], want, integer or variant == engine.QP_V4), (variant, b, got[b], want)
+    # V1 with a short partition stops early; V2 reports inf
+    if ir.T > 2:
+        short = torch.from_numpy(A[:, :ir.T - 1].copy()).to(dev)
+        got = eng.cost_v2(dc, dt, short, engine.QP_V2).cpu().numpy()
+        assert np.isinf(got).all()
+        got = eng.cost_v2(dc, dt, short, engine.QP_V1).cpu().numpy()
+        rows = [[None if c == 0xFF else int(c) for c in r[:Q]] for r in A[0, :ir.T - 1]]
+        want = float(O.cost_v1(ir.slices, ir.gate_q, ir.gate_mr, rows, Dl))
+        assert _close(got[0], want, integer)
+
+
+def test_cost_v3_rejects_bad_arguments(gpu):
+    torch, engine, eng, dev = gpu
+    ir, eu, ev, w, rng = _random_setup(20, 5, 4, True, seed=1)
+    dc, dt = engine.DeviceCircuit(ir, dev), engine.DistanceTable(engine.apsp(4, eu, ev, w), dev)
+    A = torch.zeros((1, ir.T - 1, dc.ldq), dtype=torch.uint8, device=dev)
+    from quantum_simulator_amd._lib import QplaceError
+    with pytest.raises(QplaceError):
+        eng.cost_v3(dc, dt, A)  # fewer rows than slices: IndexError in the reference
+    with pytest.raises(ValueError):
+        eng.cost_v3(dc, dt, torch.zeros((1, ir.T, 24), dtype=torch.uint8, device=dev))
+
+
+@pytest.mark.parametrize("name", SMALL_CASES)
+@pytest.mark.parametrize("kind", ["hqa", "trhqa", "gtrhqa"])
+def test_cost_matrix_bits(gpu, name, kind):
+    """Every matrix the placement loop builds on this case, bit for bit (the oracle's matrices are
+    themselves pinned to the ones the reference handed to scipy)."""
+    torch, engine, eng, dev = gpu
+    gc = load_case(name)
+    if not gc.has(kind.upper()):
+        pytest.skip("capacity too small")
+    from quantum_simulator_amd.timeslices import CircuitIR
+    ir = CircuitIR(gc.Q, gc.gate_q, gc.gate_mr, slices=gc.slices)
+    dc, dt = engine.DeviceCircuit(ir, dev), engine.DistanceTable(gc.D, dev)
+    rec = []
+    Dl = gc.D.tolist()
+    if kind == "gtrhqa":
+        O.place_gtrhqa(gc.slices, gc.gate_q, gc.gate_mr, gc.Q, gc.C, gc.cap, Dl, rec)
+    else:
+        O.place_hqa_family(gc.slices, gc.gate_q, gc.gate_mr, gc.Q, gc.C, gc.cap, Dl, kind, rec)
+    rec = rec[:400]
+    if not rec:
+        pytest.skip("no matrices on this case")
+    B = len(rec)
+    max_ops = max(len(r[1]) for r in rec)
+    t = np.array([r[0] for r in rec], np.int32)
+    a = np.zeros((B, dc.ldq), np.uint8)
+    ops = np.zeros((B, max_ops), np.int32)
+    n_ops = np.zeros(B, np.int32)
+    avail = np.zeros((B, gc.C), np.uint8)
+    n_avail = np.zeros(B, np.int32)
+    for b, (tt, rops, rav, M, live) in enumerate(rec):
+        a[b, :gc.Q] = live
+        ops[b, :len(rops)] = [ir.edge_of_gate[g] for g, _, _ in rops]
+        n_ops[b] = len(rops)
+        avail[b, :len(rav)] = rav
+        n_avail[b] = len(rav)
+    code = {"hqa": engine.QP_CM_HQA, "trhqa": engine.QP_CM_TRHQA, "gtrhqa": engine.QP_CM_GTRHQA}[kind]
+    out = eng.cost_matrix(code, dc, dt, *[torch.from_numpy(x).to(dev) for x in (t, a, ops, n_ops, avail, n_avail)])
+    out = out.cpu().numpy()
+    for b, (tt, rops, rav, M, live) in enumerate(rec):
+        want = np.array(M)
+        got = out[b, :len(rops), :len(rav)]
+        assert got.tobytes() == want.tobytes(), (name, kind, b)

@@ -117,7 +117,7 @@ def _check_place(name, placer):
         rec = []
         rows = O.place_hqa_family(gc.slices, gc.gate_q, gc.gate_mr, gc.Q, gc.C, gc.cap, D, placer.lower(), rec)
         # every recorded matrix the reference handed to scipy must occur, entry for entry
-        mine = {(len(m), np.array(m).tobytes()) for _, _, _, m in rec}
+        mine = {(len(m), np.array(m).tobytes()) for _, _, _, m, _ in rec}
         for tag, cm, r, c in gc.lsap_samples():
             if tag == placer:
                 assert (cm.shape[0], cm.tobytes()) in mine, (name, placer)
