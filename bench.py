@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Headline benchmark: timeslice cost evaluations per second on MI355X.
+
+Workload (``config.workload``): the synthetic layered circuit with 1024 qubits x 1000 timeslices
+(256 two-qubit gates per slice) on a 16x16 mesh of cores, 4096 candidate partitions per GPU, costed
+with the HQA-family definition (the cost GTRHQA reports).  One step = one pass of the cost path over
+all partitions of the rank: qp_slice_cost_v3 through the C ABI, inputs resident in HBM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--weights uniform|integer] [--partitions B]
+                    [--pmove P] [--no-cpu]
+
+For N > 1 launch with torch.distributed.run (one rank per GPU); ranks work on disjoint partitions with
+no collective in the timed region; the final mean/min reduction over ranks (one RCCL all-reduce of a
+few doubles) is done once after it and reported as ``reduce_ms``.
+
+Rank 0 prints one JSON line.  ``roofline`` prices the dominant kernel (k_cost_v3) against HBM:
+algorithmic bytes per launch / mean launch time from HIP events on the launch stream.
+``cpu_baseline`` times the CPU oracle (a port of the reference's per_timeslice_cost loop) on a bounded
+sample of the same partitions on one host core.
+"""
+import argparse
+import json
+import math
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+
+
+def make_partitions(torch, dev, B, T, Q, ldq, C, cap, pmove, seed):
+    """Seeded random-walk partitions: row 0 is the placers' block assignment (qubit i on core
+    i // cap); in every later row each qubit moves to a uniformly random core with probability
+    ``pmove`` (default: the move rate GTRHQA itself produces on this circuit)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    A = torch.zeros((B, T, ldq), dtype=torch.uint8, device=dev)
+    row = (torch.arange(Q, device=dev) // cap).clamp(max=C - 1).to(torch.uint8).expand(B, Q).contiguous()
+    A[:, 0, :Q] = row
+    for t in range(1, T):
+        move = torch.rand((B, Q), device=dev, generator=g) < pmove
+        dest = torch.randint(0, C, (B, Q), device=dev, generator=g, dtype=torch.int16).to(torch.uint8)
+        row = torch.where(move, dest, row)
+        A[:, t, :Q] = row
+    return A
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--weights", choices=["uniform", "integer"], default="uniform")
+    ap.add_argument("--partitions", type=int, default=4096, help="partitions per GPU")
+    ap.add_argument("--qubits", type=int, default=1024)
+    ap.add_argument("--slices", type=int, default=1000)
+    ap.add_argument("--pmove", type=float, default=0.25)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from quantum_simulator_amd import layered_gate_arrays
+    from quantum_simulator_amd.engine import DeviceCircuit, DistanceTable, Engine, apsp, QP_DT_U16
+    from quantum_simulator_amd.multicore import graph_tables, multicore
+    from quantum_simulator_amd.timeslices import CircuitIR
+
+    Q, T, B = args.qubits, args.slices, args.partitions
+    CX = CY = 16
+    cap = 8
+    circ_seed, weight_seed = 2025, 1234
+    q0, q1, _ = layered_gate_arrays(Q, T, 0.5, seed=circ_seed)
+    ir = CircuitIR.from_gate_tables(Q, q0, q1)
+    random.seed(weight_seed)
+    wr = (1.0, 3.0) if args.weights == "uniform" else (2.0, 2.0)
+    arch = multicore(CX, CY, ncm_qubits=4, ncp_qubits=cap, edge_weight_range=wr, network_type="mesh")
+    nodes, eu, ev, w = graph_tables(arch.network)
+    C = len(nodes)
+    D = apsp(C, eu, ev, w)
+    dc, dt, eng = DeviceCircuit(ir, dev), DistanceTable(D, dev), Engine(dev)
+    A = make_partitions(torch, dev, B, ir.T, Q, dc.ldq, C, cap, args.pmove, seed=777 + rank)
+    out = torch.empty(B, dtype=torch.float64, device=dev)
+
+    def step():
+        eng.cost_v3(dc, dt, A, out=out)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    stream = torch.cuda.current_stream(dev)
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        step()
+    ev1.record(stream)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1) / args.steps  # mean device time of one launch (+ the chunk-sum kernel)
+
+    tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
+    reduce_ms = None
+    stats = torch.stack([out.sum(), torch.tensor(float(B), dtype=torch.float64, device=dev)])
+    mn = out.min().reshape(1)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        torch.cuda.synchronize(dev)
+        r0 = time.perf_counter()
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)   # final mean cost = sum / count (main.py:103-104)
+        dist.all_reduce(mn, op=dist.ReduceOp.MIN)      # final min cost
+        torch.cuda.synchronize(dev)
+        reduce_ms = (time.perf_counter() - r0) * 1e3
+    wall = float(tmax.item())
+    mean_cost = float(stats[0].item() / stats[1].item())
+    min_cost = float(mn.item())
+
+    if rank == 0:
+        evals = world * B * ir.T * args.steps
+        value = evals / wall
+        alg_bytes = B * ir.T * Q + 4 * ir.nE + 4 * (ir.T + 1) + 8 * B + 8 * C * C
+        achieved = alg_bytes / (dev_ms * 1e-3) / 1e9
+        res = {
+            "metric": "timeslice cost evals/sec", "value": value, "unit": "evals/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u16 table / u32 sums" if dt.kind == QP_DT_U16 else "f64", "data": "synthetic",
+            "config": {"workload": f"cfg5: layered {Q}q x {ir.T} slices ({ir.nE // ir.T} cx/slice), mesh {CX}x{CY}, "
+                                   f"cap {cap}, {args.weights} weights {wr}, {B} partitions/GPU, cost V3 (HQA/TRHQA/GTRHQA)",
+                       "partitions": f"random walk from the block assignment, pmove={args.pmove}",
+                       "seeds": {"circuit": circ_seed, "weights": weight_seed, "partitions": "777+rank"},
+                       "table": "uint16 in LDS" if dt.kind == QP_DT_U16 else "f64 (LDS when C*C*8 fits, else L2)"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_cost_v3",
+                         "alg_bytes_per_launch": alg_bytes, "kernel_ms": dev_ms},
+            "mean_cost": mean_cost, "min_cost": min_cost, "reduce_ms": reduce_ms,
+        }
+        if world == 1 and not args.no_cpu:
+            from oracle import placer_oracle as O
+            Dl = D.tolist()
+            gpu_costs = out.cpu().numpy()
+            nsample, t_cpu, done = 0, 0.0, 0
+            sample = A[:32, :, :Q].cpu().numpy()
+            while t_cpu < args.cpu_seconds and nsample < len(sample):
+                rows = sample[nsample].tolist()
+                c0 = time.perf_counter()
+                want = O.cost_v3(ir.slices, ir.gate_q, ir.gate_mr, rows, Dl)
+                t_cpu += time.perf_counter() - c0
+                got = float(gpu_costs[nsample])
+                nterms = ir.nE + (ir.T - 2) * Q
+                tol = 0.0 if dt.kind == QP_DT_U16 else max(1e-12, nterms * 2.0 ** -53) * abs(want)
+                if abs(got - want) > tol:
+                    raise SystemExit(f"parity failure on sample partition {nsample}: gpu {got!r} oracle {want!r}")
+                nsample += 1
+            res["cpu_baseline"] = {"value": nsample * ir.T / t_cpu, "unit": "evals/s", "cores": 1, "kind": "port",
+                                   "sample": f"{nsample} of this run's partitions x {ir.T} slices through the CPU oracle "
+                                             f"(oracle/placer_oracle.py cost_v3, precomputed distance matrix), "
+                                             f"{t_cpu:.1f} s; GPU results checked against it",
+                                   "host_cpus": os.cpu_count(), "affinity": len(os.sched_getaffinity(0))}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -173,6 +173,24 @@ def cost_v3(slices, gate_q, gate_mr, part, D):
     return total
 
 
+def cost_v3_terms(slices, gate_q, gate_mr, part, D):
+    """The individual addends of ``cost_v3`` in the reference's order (for error-bound checks: the
+    reference's left-to-right float sum of n terms carries a relative error of up to n * 2**-53)."""
+    terms = []
+    for i, sl in enumerate(slices):
+        row = part[i]
+        for g in sl:
+            qs = gate_q[g]
+            if len(qs) == 2 and not gate_mr[g] and row[qs[0]] != row[qs[1]]:
+                terms.append(D[row[qs[0]]][row[qs[1]]])
+    for i in range(2, len(slices)):
+        prev, cur = part[i - 1], part[i]
+        for q in range(len(cur)):
+            if cur[q] != prev[q]:
+                terms.append(D[prev[q]][cur[q]])
+    return terms
+
+
 # ------------------------------------------------------------------------------------------------
 # A3 / A4  cost V1, V2, V4
 # ------------------------------------------------------------------------------------------------

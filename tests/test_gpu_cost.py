@@ -1,6 +1,8 @@
 """GPU parity tests: the HIP kernels, called through the C ABI, against the CPU oracle and the
 reference-generated fixtures.  Integer distance tables must agree exactly; fp64 tables within 1e-12
 relative (the sums are formed in a different order from the reference's sequential loop)."""
+import math
+
 import numpy as np
 import pytest
 
@@ -22,12 +24,14 @@ def gpu():
     return torch, engine, engine.Engine(dev), dev
 
 
-def _close(got, want, exact):
+def _close(got, want, exact, nterms=0):
+    """Exact for integer tables.  Otherwise 1e-12 relative, widened to the reference's own
+    left-to-right summation error bound (nterms * 2**-53) when it adds more than ~9000 terms."""
     if np.isinf(want):
         return np.isinf(got)
     if exact:
         return got == want
-    return abs(got - want) <= RTOL * max(1.0, abs(want))
+    return abs(got - want) <= max(RTOL, nterms * 2.0 ** -53) * max(1.0, abs(want))
 
 
 def _pad(arr, ldq):
@@ -50,9 +54,12 @@ def test_cost_v3_golden(gpu, name):
         if not gc.has(p):
             continue
         A = torch.from_numpy(_pad(gc.part(p), dc.ldq)[None].copy()).to(dev)
+        terms = O.cost_v3_terms(gc.slices, gc.gate_q, gc.gate_mr, gc.part(p).tolist(), gc.D.tolist())
         for table in ("packed", "f64"):
             got = float(eng.cost_v3(dc, dt, A, table=table).cpu()[0])
-            assert _close(got, gc.cost(p), exact), (p, table, got, gc.cost(p))
+            assert _close(got, gc.cost(p), exact, len(terms)), (p, table, got, gc.cost(p))
+            # against the correctly rounded sum the kernel is inside 1e-12 however many terms there are
+            assert _close(got, math.fsum(terms), exact), (p, table, got, math.fsum(terms))
     # the three partitions of equal length as one batch, plus a repeat for run-to-run determinism
     parts = [gc.part(p) for p in ("HQA", "TRHQA") if gc.has(p)]
     if parts:
@@ -76,9 +83,9 @@ def test_cost_v2_v1_v4_golden(gpu, name):
     for p in ("BFS", "RANDOM"):
         A = torch.from_numpy(_pad(gc.part(p), dc.ldq)[None].copy()).to(dev)
         got = float(eng.cost_v2(dc, dt, A, engine.QP_V2).cpu()[0])
-        assert _close(got, gc.cost(p), exact), (p, got, gc.cost(p))
+        assert _close(got, gc.cost(p), exact, 2 * ir.nV), (p, got, gc.cost(p))
         got = float(eng.cost_v2(dc, dt, A, engine.QP_V1).cpu()[0])
-        assert _close(got, gc.cost_v1(p), exact), (p, "v1", got, gc.cost_v1(p))
+        assert _close(got, gc.cost_v1(p), exact, 2 * ir.nV), (p, "v1", got, gc.cost_v1(p))
         try:
             want = O.cost_v4(gc.slices, gc.gate_q, gc.gate_mr, gc.part_rows(p), gc.hops.tolist())
         except O.CostError:
@@ -89,7 +96,7 @@ def test_cost_v2_v1_v4_golden(gpu, name):
         if gc.has(p):
             A = torch.from_numpy(_pad(gc.part(p), dc.ldq)[None].copy()).to(dev)
             got = float(eng.cost_v2(dc, dt, A, engine.QP_V1).cpu()[0])
-            assert _close(got, gc.cost_v1(p), exact), (p, "v1 dense", got)
+            assert _close(got, gc.cost_v1(p), exact, 2 * ir.nV), (p, "v1 dense", got)
 
 
 SHAPES = [  # Q, T, C, B, integer weights
