@@ -56,6 +56,24 @@ __device__ inline uint32_t stage_table(uint8_t* smem, const void* table, uint32_
     return padded;
 }
 
+// Same, but every row is placed at a pitch of 256 entries so that (from << 8 | to) indexes the table.
+template <typename E>
+__device__ inline uint32_t stage_table_pitch256(uint8_t* smem, const void* table, int C) {
+    const E* src = static_cast<const E*>(table);
+    E* dst = reinterpret_cast<E*>(smem);
+    for (int k = threadIdx.x; k < C * 256; k += blockDim.x) {
+        const int r = k >> 8, c = k & 255;
+        dst[k] = c < C ? src[r * C + c] : E(0);
+    }
+    __syncthreads();
+    return (uint32_t)(C * 256 * sizeof(E));
+}
+
+// Where the distance table lives while a cost kernel runs.
+constexpr int kTabLds256 = 0;  // LDS, row pitch 256 entries: index = from << 8 | to
+constexpr int kTabLdsC = 1;    // LDS, row pitch C
+constexpr int kTabGlobal = 2;  // device memory (L2-resident), row pitch C
+
 // ------------------------------------------------------------------------------------------------
 // Cost V3: dense partitions, HQA-family definition.
 //
@@ -84,7 +102,7 @@ struct V3Args {
     uint32_t table_bytes;
 };
 
-template <int KIND, bool TAB_LDS>
+template <int KIND, int TABMODE>
 __global__ __launch_bounds__(kV3Threads) void k_cost_v3(V3Args p) {
     extern __shared__ __align__(16) uint8_t smem[];
     using E = typename Tab<KIND>::elem;
@@ -93,19 +111,49 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3(V3Args p) {
     const int wave = threadIdx.x / kWave;
     uint32_t tab_off = 0;
     const E* tab;
-    if constexpr (TAB_LDS) {
+    if constexpr (TABMODE == kTabLds256) {
+        tab_off = stage_table_pitch256<E>(smem, p.table, p.C);
+        tab = reinterpret_cast<const E*>(smem);
+    } else if constexpr (TABMODE == kTabLdsC) {
         tab_off = stage_table(smem, p.table, p.table_bytes);
         tab = reinterpret_cast<const E*>(smem);
     } else {
         tab = static_cast<const E*>(p.table);
     }
-    const int ldq = p.ldq, G = p.G, lpr = p.lpr, C = p.C;
+    const int ldq = p.ldq, G = p.G, lpr = p.lpr;
+    const uint32_t C = (uint32_t)p.C;
     uint8_t* strip = smem + tab_off + (size_t)wave * (G + 1) * ldq;  // [row before][G rows]
     const int nact = G * lpr;
     const bool lane_on = lane < nact;
     const int lrow = lane / lpr;
     const int lq0 = (lane - lrow * lpr) * 16;
     const int nvalid_row = min(16, max(0, p.Q - lq0));  // qubits of this lane's piece that exist
+    // byte masks of the piece's four dwords; all ones except in the last piece of a ragged row
+    uint32_t keep[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const int nb = min(4, max(0, nvalid_row - 4 * w));
+        keep[w] = nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u);
+    }
+
+    // distance of one (from, to) pair
+    auto pair_at = [&](uint32_t from, uint32_t to) -> Acc {
+        if constexpr (TABMODE == kTabLds256) return tab[(from << 8) | to];
+        else return tab[__umul24(from, C) + to];
+    };
+    // sum over the four byte lanes of (from dword, to dword)
+    auto four = [&](uint32_t pf, uint32_t cf) -> Acc {
+        if constexpr (TABMODE == kTabLds256) {
+            const uint32_t lo = __builtin_amdgcn_perm(pf, cf, 0x05010400u);  // (p0<<8|c0) | (p1<<8|c1) << 16
+            const uint32_t hi = __builtin_amdgcn_perm(pf, cf, 0x07030602u);
+            return (Acc)tab[lo & 0xFFFFu] + (Acc)tab[lo >> 16] + (Acc)tab[hi & 0xFFFFu] + (Acc)tab[hi >> 16];
+        } else {
+            Acc s = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s += (Acc)tab[__umul24((pf >> (8 * j)) & 0xFFu, C) + ((cf >> (8 * j)) & 0xFFu)];
+            return s;
+        }
+    };
 
     for (int64_t it = (int64_t)blockIdx.x * kV3Waves + wave; it < p.nitems; it += (int64_t)gridDim.x * kV3Waves) {
         const int chunk = (int)(it / p.B);
@@ -149,31 +197,24 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3(V3Args p) {
                     *reinterpret_cast<uint4*>(strip + ldq + lane * 16) = cur;
                     prv = *reinterpret_cast<const uint4*>(strip + lane * 16);
                 }
-                // movement: rows 2..T-1, previous row -> this row
+                // movement: rows 2..T-1, previous row -> this row.  Lanes that take no part look up
+                // (0, 0), which is on the zero diagonal like every qubit that stayed where it was.
                 const int row = rg + lrow;
-                const int nvalid = (lane_on && row >= 2 && row < r1) ? nvalid_row : 0;
-                const uint32_t cw[4] = {cur.x, cur.y, cur.z, cur.w};
-                const uint32_t pw[4] = {prv.x, prv.y, prv.z, prv.w};
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const int nb = min(4, max(0, nvalid - 4 * w));
-                    const uint32_t m = nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u);
-                    const uint32_t c4 = cw[w] & m, p4 = pw[w] & m;
-                    if (__builtin_amdgcn_ballot_w64(c4 != p4) == 0) continue;  // nobody in this column moved
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const uint32_t pc = (p4 >> (8 * j)) & 0xFFu, cc = (c4 >> (8 * j)) & 0xFFu;
-                        acc += tab[pc * C + cc];
-                    }
-                }
+                const bool mv = lane_on && row >= 2 && row < r1;
+                const uint32_t c0 = mv ? cur.x & keep[0] : 0u, p0 = mv ? prv.x & keep[0] : 0u;
+                const uint32_t c1 = mv ? cur.y & keep[1] : 0u, p1 = mv ? prv.y & keep[1] : 0u;
+                const uint32_t c2 = mv ? cur.z & keep[2] : 0u, p2 = mv ? prv.z & keep[2] : 0u;
+                const uint32_t c3 = mv ? cur.w & keep[3] : 0u, p3 = mv ? prv.w & keep[3] : 0u;
+                const bool moved = ((c0 ^ p0) | (c1 ^ p1) | (c2 ^ p2) | (c3 ^ p3)) != 0;
+                if (__builtin_amdgcn_ballot_w64(moved) != 0)
+                    acc += (four(p0, c0) + four(p1, c1)) + (four(p2, c2) + four(p3, c3));
                 // counted two-qubit gates of these slices
                 const int e0 = __builtin_amdgcn_readfirstlane(p.sep[rg]);
                 const int e1 = __builtin_amdgcn_readfirstlane(p.sep[min(rg + G, r1)]);
                 for (int e = e0 + lane; e < e1; e += kWave) {
                     const QpEdge ed = p.edges[e];
                     const uint8_t* rowp = strip + ldq + (ed.t - rg) * ldq;
-                    const uint32_t au = rowp[ed.u], av = rowp[ed.v];
-                    acc += tab[au * C + av];
+                    acc += pair_at(rowp[ed.u], rowp[ed.v]);
                 }
                 // the last row of the group becomes "the row before" of the next group
                 if (lane_on && lrow == G - 1) *reinterpret_cast<uint4*>(strip + lq0) = cur;
@@ -448,12 +489,24 @@ extern "C" int qp_slice_cost_v3(const QpCircuit* circ, const QpDTable* dt, const
 
     if (narrow) {
         const size_t strips = (size_t)kV3Waves * (p.G + 1) * ldq;
-        const bool tab_lds = tab_padded + strips <= (size_t)kLdsBytes;
-        const size_t lds = strips + (tab_lds ? tab_padded : 0);
+        const size_t tab256 = (size_t)dt->C * 256 * esz;
+        int mode = kTabGlobal;
+        size_t lds = strips;
+        if (tab256 + strips <= (size_t)kLdsBytes) {
+            mode = kTabLds256;
+            lds += tab256;
+        } else if (tab_padded + strips <= (size_t)kLdsBytes) {
+            mode = kTabLdsC;
+            lds += tab_padded;
+        }
         const unsigned grid = (unsigned)std::min<int64_t>(cus, (p.nitems + kV3Waves - 1) / kV3Waves);
         void (*kern)(V3Args) = nullptr;
-        if (dt->kind == QP_DT_F64) kern = tab_lds ? k_cost_v3<QP_DT_F64, true> : k_cost_v3<QP_DT_F64, false>;
-        else kern = tab_lds ? k_cost_v3<QP_DT_U16, true> : k_cost_v3<QP_DT_U16, false>;
+        if (dt->kind == QP_DT_F64)
+            kern = mode == kTabLds256 ? k_cost_v3<QP_DT_F64, kTabLds256>
+                 : mode == kTabLdsC   ? k_cost_v3<QP_DT_F64, kTabLdsC> : k_cost_v3<QP_DT_F64, kTabGlobal>;
+        else
+            kern = mode == kTabLds256 ? k_cost_v3<QP_DT_U16, kTabLds256>
+                 : mode == kTabLdsC   ? k_cost_v3<QP_DT_U16, kTabLdsC> : k_cost_v3<QP_DT_U16, kTabGlobal>;
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         kern<<<grid, kV3Threads, lds, stream>>>(p);
     } else {
