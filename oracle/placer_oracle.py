@@ -516,6 +516,53 @@ def _argmin_first(vals):
     return bi
 
 
+def gtrhqa_rounds(M):
+    """GTRHQA_placer.py:128-254 on one cost matrix (list of rows): (op, core column) pairs in the
+    order the reference applies them."""
+    HUGE = 1e12
+    nops, nav = len(M), len(M[0])
+    core_free = [True] * nav
+    op_left = [True] * nops
+    core_of_op = [-1] * nops
+    out = []
+    rounds = 0
+    while any(op_left) and any(core_free) and rounds < min(nav, nops) + 2:
+        rounds += 1
+        cols = [j for j in range(nav) if core_free[j]]
+        rows = [k for k in range(nops) if op_left[k]]
+        if not any(isfinite(M[k][j]) for k in rows for j in cols):
+            break
+        choice = []
+        for k in rows:
+            masked = [M[k][j] if isfinite(M[k][j]) else HUGE for j in cols]
+            r = _argmin_first(masked)
+            choice.append((cols[r], masked[r], k))
+        for j in sorted(set(c for c, _, _ in choice)):
+            group = [(v, k) for c, v, k in choice if c == j]
+            k = group[_argmin_first([v for v, _ in group])][1]
+            if core_of_op[k] != -1 or not core_free[j] or not isfinite(M[k][j]):
+                continue
+            core_of_op[k] = j
+            core_free[j] = False
+            op_left[k] = False
+            out.append((k, j))
+    left_cores = [j for j in range(nav) if core_free[j]]
+    for k in range(nops):
+        if core_of_op[k] != -1:
+            continue
+        if not left_cores:
+            break
+        vals = [M[k][j] for j in left_cores]
+        if not any(isfinite(v) for v in vals):
+            continue
+        r = _argmin_first([v if isfinite(v) else HUGE for v in vals])
+        j = left_cores[r]
+        core_of_op[k] = j
+        out.append((k, j))
+        left_cores.remove(j)
+    return out
+
+
 def place_gtrhqa(slices, gate_q, gate_mr, Q, C, cap, D, record=None):
     """GTRHQA_placer.py:20-267.  Returns T+1 rows: the loop starts at slice 0, slice t reads row
     t-1 (row 0 for t = 0) and appends row t+1."""
@@ -524,7 +571,6 @@ def place_gtrhqa(slices, gate_q, gate_mr, Q, C, cap, D, record=None):
     T = len(slices)
     init = [int(i / cap) for i in range(Q)]
     part = [init]
-    HUGE = 1e12
     for t in range(T):
         prev = part[t - 1] if t > 0 else init
         a = list(prev)
@@ -546,53 +592,10 @@ def place_gtrhqa(slices, gate_q, gate_mr, Q, C, cap, D, record=None):
         M = [[entry_gtrhqa(q1, q2, c, a, D) for c in avail] for _, q1, q2 in ops]
         if record is not None:
             record.append((t, list(ops), list(avail), [list(r) for r in M], list(a)))
-        nops, nav = len(ops), len(avail)
-        core_free = [True] * nav
-        op_left = [True] * nops
-        core_of_op = [-1] * nops
-
-        def assign(k, j):
-            core_of_op[k] = j
-            core_free[j] = False
-            op_left[k] = False
+        for k, j in gtrhqa_rounds(M):
             _, q1, q2 = ops[k]
             a[q1] = avail[j]
             a[q2] = avail[j]
-
-        rounds = 0
-        while any(op_left) and any(core_free) and rounds < min(nav, nops) + 2:
-            rounds += 1
-            cols = [j for j in range(nav) if core_free[j]]
-            rows = [k for k in range(nops) if op_left[k]]
-            if not any(isfinite(M[k][j]) for k in rows for j in cols):
-                break
-            choice = []
-            for k in rows:
-                masked = [M[k][j] if isfinite(M[k][j]) else HUGE for j in cols]
-                r = _argmin_first(masked)
-                choice.append((cols[r], masked[r], k))
-            for j in sorted(set(c for c, _, _ in choice)):
-                group = [(v, k) for c, v, k in choice if c == j]
-                k = group[_argmin_first([v for v, _ in group])][1]
-                if core_of_op[k] != -1 or not core_free[j] or not isfinite(M[k][j]):
-                    continue
-                assign(k, j)
-        left_cores = [j for j in range(nav) if core_free[j]]
-        for k in range(nops):
-            if core_of_op[k] != -1:
-                continue
-            if not left_cores:
-                break
-            vals = [M[k][j] for j in left_cores]
-            if not any(isfinite(v) for v in vals):
-                continue
-            r = _argmin_first([v if isfinite(v) else HUGE for v in vals])
-            j = left_cores[r]
-            core_of_op[k] = j
-            _, q1, q2 = ops[k]
-            a[q1] = avail[j]
-            a[q2] = avail[j]
-            left_cores.remove(j)
         part.append(a)
     return part
 

@@ -1,0 +1,496 @@
+"""Placer plug-ins with the reference's names and method signatures (main.py:36-48,85-97):
+
+    placer.place_per_timeslice(circuit, multicore_arch) -> list[dict[qubit -> core node]]
+    placer.per_timeslice_cost(circuit, partition, multicore_arch) -> float
+
+The sequential control flow of each placement algorithm stays on the host, as in the reference; what
+it evaluates — op x core cost matrices, the assignment solve, the communication-cost sums, the
+core-distance matrix — comes from libqplace.so (HIP kernels + host C++ behind include/qplace.h).
+Nothing here computes a cost on the CPU in Python.
+"""
+from __future__ import annotations
+
+import random
+from collections import deque
+
+import numpy as np
+
+from . import engine as E
+from ._lib import QP_ABSENT, QP_CM_GTRHQA, QP_CM_HQA, QP_CM_TRHQA, QP_V1, QP_V2, QP_V4
+from .multicore import graph_tables
+from .timeslices import CircuitIR, circuit_ir
+
+
+class _ArchTables:
+    """Per-architecture state: node order, all-pairs distances (host), device tables on demand."""
+
+    def __init__(self, network, device=None):
+        self.nodes, self.eu, self.ev, self.w = graph_tables(network)
+        self.index = {n: i for i, n in enumerate(self.nodes)}
+        self.C = len(self.nodes)
+        self.device = device
+        self.D = E.apsp(self.C, self.eu, self.ev, self.w)
+        self._table = None
+        self._hops = None
+
+    @property
+    def table(self):
+        if self._table is None:
+            self._table = E.DistanceTable(self.D, self.device)
+        return self._table
+
+    @property
+    def hop_table(self):
+        if self._hops is None:
+            self._hops = E.DistanceTable(E.hops(self.C, self.eu, self.ev), self.device)
+        return self._hops
+
+    @staticmethod
+    def fingerprint(network):
+        return (id(network), network.number_of_nodes(),
+                tuple(d.get("weight", 1) for _, _, d in network.edges(data=True)))
+
+
+class _Context:
+    """Everything a placer call needs for one (circuit, architecture) pair, cached on the placer."""
+
+    def __init__(self, circuit, arch, device):
+        self.device = device
+        self.ir: CircuitIR = circuit_ir(circuit)
+        self.dc = E.DeviceCircuit(self.ir, device)
+        self.arch = _ArchTables(arch.network, device)
+        self.eng = E.get_engine(device)
+        self.qindex = {q: i for i, q in enumerate(self.ir.qubits)}
+        self._cm_bufs = None
+
+    # -- partitions -------------------------------------------------------------------------------
+    def partition_array(self, partition, dense, rows=None):
+        """list[dict] -> uint8 [Tp, ldq].  ``dense``: every circuit qubit must be in every used row
+        (a missing key is a KeyError in the reference's HQA-family cost)."""
+        Q, ldq = self.ir.Q, self.dc.ldq
+        n = len(partition) if rows is None else min(rows, len(partition))
+        out = np.full((len(partition), ldq), QP_ABSENT if not dense else 0, np.uint8)
+        out[:, Q:] = 0
+        idx, qidx = self.arch.index, self.qindex
+        for t, row in enumerate(partition):
+            if dense and t < n and len(row) < Q:
+                missing = next(q for q in self.ir.qubits if q not in row)
+                raise KeyError(missing)
+            for q, node in row.items():
+                k = qidx.get(q)
+                if k is None:
+                    continue
+                out[t, k] = QP_ABSENT if node is None else idx[node]
+        return out
+
+    def rows_to_partition(self, rows):
+        """uint8 rows -> list of dicts keyed by the circuit's qubit objects, valued by node labels,
+        in circuit.qubits order (the reference's dicts are built in that order, HQA_placer.py:40-44)."""
+        qs, nodes = self.ir.qubits, self.arch.nodes
+        return [{qs[i]: nodes[c] for i, c in enumerate(r)} for r in (row[: self.ir.Q].tolist() for row in rows)]
+
+    # -- device calls -----------------------------------------------------------------------------
+    def cost_matrix(self, kind, t, a, op_edges, avail):
+        """One op x core matrix for the live assignment ``a`` (uint8 [Q])."""
+        import torch
+        n_ops, n_av, C = len(op_edges), len(avail), self.arch.C
+        dev = self.device
+        ab = np.zeros((1, self.dc.ldq), np.uint8)
+        ab[0, : self.ir.Q] = a
+        av = np.zeros((1, C), np.uint8)
+        av[0, :n_av] = avail
+        out = self.eng.cost_matrix(
+            kind, self.dc, self.arch.table,
+            torch.tensor([t], dtype=torch.int32, device=dev), torch.from_numpy(ab).to(dev),
+            torch.tensor([list(op_edges)], dtype=torch.int32, device=dev),
+            torch.tensor([n_ops], dtype=torch.int32, device=dev), torch.from_numpy(av).to(dev),
+            torch.tensor([n_av], dtype=torch.int32, device=dev))
+        return out[0, :n_ops, :n_av].cpu().numpy()
+
+    def cost(self, arr, variant, table=None):
+        import torch
+        A = torch.from_numpy(np.ascontiguousarray(arr[None])).to(self.device)
+        tab = table if table is not None else self.arch.table
+        if variant == "v3":
+            out = self.eng.cost_v3(self.dc, tab, A)
+        else:
+            out = self.eng.cost_v2(self.dc, tab, A, variant)
+        return float(out.cpu()[0])
+
+
+class BasePlacer:
+    """Common services; subclasses provide ``place_per_timeslice``."""
+
+    def __init__(self, device=None):
+        self.name = "BasePlacer"
+        self._device = device
+        self._ctx_key = None
+        self._ctx = None
+
+    # -- context ----------------------------------------------------------------------------------
+    def _context(self, circuit, arch) -> _Context:
+        key = (id(circuit), sum(1 for _ in circuit), _ArchTables.fingerprint(arch.network))
+        if self._ctx_key != key:
+            dev = self._device if self._device is not None else E.default_device()
+            self._ctx = _Context(circuit, arch, dev)
+            self._ctx_key = key
+            self.node_index = self._ctx.arch.index
+            self._dist_matrix = self._ctx.arch.D
+        return self._ctx
+
+    # -- reference surface ------------------------------------------------------------------------
+    def break_into_timeslices(self, circuit):
+        """Timeslices as lists of commands, same membership and order as Placer.py:14-61."""
+        return circuit_ir(circuit).command_slices()
+
+    def get_weighted_distance(self, multicore_arch, node1, node2):
+        """Weighted shortest-path distance node1 -> node2 (Placer.py:63-76), read from the all-pairs
+        table qp_apsp_f64 fills (same bits as a fresh search from node1)."""
+        fp = _ArchTables.fingerprint(multicore_arch.network)
+        if self._ctx is not None and self._ctx_key[2] == fp:
+            tabs = self._ctx.arch
+        else:
+            if getattr(self, "_dist_key", None) != fp:
+                self._dist_tabs = _ArchTables(multicore_arch.network)
+                self._dist_key = fp
+            tabs = self._dist_tabs
+        return self._as_distance(tabs.D[tabs.index[node1], tabs.index[node2]])
+
+    @staticmethod
+    def _as_distance(x):
+        x = float(x)
+        return int(x) if x == 0 else x
+
+    def per_timeslice_cost(self, circuit, partition, multicore_arch):
+        """BasePlacer.per_timeslice_cost (Placer.py:78-120) on the device."""
+        ctx = self._context(circuit, multicore_arch)
+        if len(partition) == 0:
+            return 0
+        arr = ctx.partition_array(partition, dense=False)
+        return self._finish(ctx.cost(arr, QP_V1))
+
+    def _finish(self, x):
+        if x == float("inf") and np.isfinite(self._ctx.arch.D).all():
+            # the reference raises inside its loop here; main.py:99-102 records inf for the repeat
+            raise KeyError("qubit missing from the partition where the cost function needs it")
+        return x
+
+    def place_per_timeslice(self, circuit, multicore_arch):
+        raise NotImplementedError("Subclasses must implement place_per_timeslice method")
+
+    def get_qpu_capacity(self, qpu_node, multicore_arch):
+        return multicore_arch.network.nodes[qpu_node]["qpu"].available_qubits
+
+
+# ------------------------------------------------------------------------------------------------
+# HQA / TRHQA / GTRHQA
+# ------------------------------------------------------------------------------------------------
+
+class _HqaFamily(BasePlacer):
+    _kind = QP_CM_HQA
+
+    def per_timeslice_cost(self, circuit, partition, multicore_arch):
+        """HQA_placer.py:259-287: crossing gates of every slice + moves between rows i-1 and i for
+        i >= 2, with row i standing for slice i."""
+        ctx = self._context(circuit, multicore_arch)
+        T = ctx.ir.T
+        if len(partition) < T:
+            raise IndexError("list index out of range")
+        arr = ctx.partition_array(partition, dense=True, rows=T)
+        return ctx.cost(arr, "v3")
+
+    @staticmethod
+    def _initial(Q, cap):
+        # HQA_placer.py:40-44: qubit i (circuit.qubits order) starts on core int(i / cap)
+        return np.array([int(i / cap) for i in range(Q)], np.uint8)
+
+    def _check_capacity(self, Q, C, cap):
+        if Q > C * cap:
+            raise ValueError(f"Not enough space: {Q} qubits need {C * cap} total slots")
+
+    def place_per_timeslice(self, circuit, multicore_arch):
+        ctx = self._context(circuit, multicore_arch)
+        return ctx.rows_to_partition(self.place_rows(ctx, multicore_arch.qpu_qubit_num))
+
+    def place_rows(self, ctx: _Context, cap: int):
+        """HQA_placer.py:56-176 / TRHQA_placer.py:62-228 on index arrays.  Returns T uint8 rows."""
+        ir, C = ctx.ir, ctx.arch.C
+        Q, T = ir.Q, ir.T
+        self._check_capacity(Q, C, cap)
+        D = ctx.arch.D
+        rows = [self._initial(Q, cap)]
+        for t in range(1, T):
+            prev = rows[t - 1]
+            a = prev.copy()
+            ops = [op for op in ir.slice_ops(t) if prev[op[1]] != prev[op[2]]]
+            if not ops:
+                rows.append(a)
+                continue
+            occ = np.bincount(a, minlength=C).astype(np.int64)
+            remaining = ops
+            budget = len(ops) + 1
+            spent = 0
+            while remaining and spent < budget:
+                spent += 1
+                avail = np.flatnonzero(occ <= cap - 2)
+                if avail.size == 0:
+                    self._make_space(a, occ, cap, C, D)
+                    continue
+                M = ctx.cost_matrix(self._kind, t, a, [e for e, _, _ in remaining], avail)
+                try:
+                    rr, cc = E.lsap(M)
+                except ValueError:  # the reference swallows the solver's exception and stops the slice
+                    break
+                taken = set()
+                for i, j in zip(rr.tolist(), cc.tolist()):
+                    if M[i, j] != np.inf:
+                        _, u, v = remaining[i]
+                        core = int(avail[j])
+                        occ[a[u]] -= 1
+                        occ[a[v]] -= 1
+                        a[u] = core
+                        a[v] = core
+                        occ[core] += 2
+                        taken.add(i)
+                remaining = [op for k, op in enumerate(remaining) if k not in taken]
+            rows.append(a)
+        return rows
+
+    @staticmethod
+    def _make_space(a, occ, cap, C, D):
+        """HQA_placer.py:180-204: from every core above cap-2, move up to two of its qubits (lowest
+        qubit index first) to the nearest core with room, ties by lower occupancy then node order."""
+        for core in range(C):
+            if occ[core] > cap - 2:
+                inside = np.flatnonzero(a == core)[:2]
+                for q in inside.tolist():
+                    cand = [(D[core, tc], occ[tc], tc) for tc in range(C) if occ[tc] < cap - 1 and tc != core]
+                    if cand:
+                        cand.sort(key=lambda x: (x[0], x[1]))
+                        tc = cand[0][2]
+                        a[q] = tc
+                        occ[core] -= 1
+                        occ[tc] += 1
+                    if occ[core] <= cap - 2:
+                        break
+
+
+class hqa_placer(_HqaFamily):
+    _kind = QP_CM_HQA
+
+    def __init__(self, device=None):
+        super().__init__(device)
+        self.name = "HQA"
+
+
+class trhqa_placer(_HqaFamily):
+    _kind = QP_CM_TRHQA
+
+    def __init__(self, device=None):
+        super().__init__(device)
+        self.name = "TRHQA"
+
+
+class gtrhqa_placer(_HqaFamily):
+    _kind = QP_CM_GTRHQA
+
+    def __init__(self, device=None):
+        super().__init__(device)
+        self.name = "GTRHQA"
+
+    def place_rows(self, ctx: _Context, cap: int):
+        """GTRHQA_placer.py:62-265.  Returns T+1 rows: slice t starts from row t-1 (row 0 for t = 0)
+        and its result is appended as row t+1, exactly as the reference's loop does."""
+        ir, C = ctx.ir, ctx.arch.C
+        Q, T = ir.Q, ir.T
+        self._check_capacity(Q, C, cap)
+        init = self._initial(Q, cap)
+        rows = [init]
+        for t in range(T):
+            prev = rows[t - 1] if t > 0 else init
+            a = prev.copy()
+            ops = [op for op in ir.slice_ops(t) if prev[op[1]] != prev[op[2]]]
+            if ops:
+                occ = np.bincount(a, minlength=C)
+                avail = np.flatnonzero(occ <= cap - 2)
+                if avail.size:
+                    M = ctx.cost_matrix(QP_CM_GTRHQA, t, a, [e for e, _, _ in ops], avail)
+                    for k, j in greedy_rounds(M):
+                        _, u, v = ops[k]
+                        a[u] = avail[j]
+                        a[v] = avail[j]
+            rows.append(a)
+        return rows
+
+
+def greedy_rounds(M: np.ndarray):
+    """The assignment rule of GTRHQA_placer.py:128-254 on one cost matrix: in each round every
+    unassigned op bids for its cheapest free core (first minimum); a core takes the cheapest bidder
+    (first minimum, ops in index order); at most min(ops, cores) + 2 rounds, then leftovers take their
+    cheapest remaining core in op order.  Yields (op, core column) pairs in application order."""
+    nops, nav = M.shape
+    finite = np.isfinite(M)
+    Mm = np.where(finite, M, 1e12)
+    op_left = np.ones(nops, bool)
+    core_free = np.ones(nav, bool)
+    out = []
+    rounds = 0
+    while op_left.any() and core_free.any() and rounds < min(nav, nops) + 2:
+        rounds += 1
+        cols = np.flatnonzero(core_free)
+        rws = np.flatnonzero(op_left)
+        if not finite[np.ix_(rws, cols)].any():
+            break
+        sub = Mm[np.ix_(rws, cols)]
+        rel = np.argmin(sub, axis=1)
+        bid = sub[np.arange(len(rws)), rel]
+        target = cols[rel]
+        for core in np.unique(target):
+            who = np.flatnonzero(target == core)
+            k = int(rws[who[int(np.argmin(bid[who]))]])
+            if not finite[k, core]:
+                continue
+            op_left[k] = False
+            core_free[core] = False
+            out.append((k, int(core)))
+    left = [int(j) for j in np.flatnonzero(core_free)]
+    for k in np.flatnonzero(op_left).tolist():
+        if not left:
+            break
+        vals = M[k, left]
+        ok = np.isfinite(vals)
+        if not ok.any():
+            continue
+        j = left[int(np.argmin(np.where(ok, vals, 1e12)))]
+        out.append((k, j))
+        left.remove(j)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# BFS / Random: host placement driven by Python's global ``random`` stream, device cost
+# ------------------------------------------------------------------------------------------------
+
+class _SparsePlacer(BasePlacer):
+    def per_timeslice_cost(self, circuit, partition, multicore_arch):
+        """BFS_placer.py:202-239 == Random_placer.py:178-213."""
+        ctx = self._context(circuit, multicore_arch)
+        if len(partition) < ctx.ir.T:
+            raise IndexError("list index out of range")
+        return self._finish(ctx.cost(ctx.partition_array(partition, dense=False), QP_V2))
+
+
+class random_placer(_SparsePlacer):
+    def __init__(self, device=None):
+        super().__init__(device)
+        self.name = "RANDOM"
+
+    def place_per_timeslice(self, circuit, multicore_arch):
+        """Random_placer.py:25-59: per slice, every active qubit (in ``list(set(...))`` order) draws
+        ``random.choice`` over the cores that still have room."""
+        net = multicore_arch.network
+        cap = multicore_arch.qpu_qubit_num
+        nodes = list(net.nodes())
+        result = []
+        for layer in self.break_into_timeslices(circuit):
+            for n in nodes:
+                net.nodes[n]["qpu"].available_qubits = cap
+            room = {n: cap for n in nodes}
+            members = set()
+            for cmd in layer:
+                members.update(cmd.qubits)
+            placed = {}
+            for q in list(members):
+                if q not in placed:
+                    open_nodes = [n for n in nodes if room[n] > 0]
+                    if open_nodes:
+                        n = random.choice(open_nodes)
+                        placed[q] = n
+                        room[n] -= 1
+            for n in nodes:
+                net.nodes[n]["qpu"].available_qubits = room[n]
+            result.append(placed)
+        return result
+
+
+class bfs_placer(_SparsePlacer):
+    def __init__(self, device=None):
+        super().__init__(device)
+        self.name = "BFS"
+
+    def place_per_timeslice(self, circuit, multicore_arch):
+        """BFS_placer.py:101-200.  Two-qubit gates go to the first core with two free slots, else to
+        the closest pair of cores with one free slot each; single-qubit gates draw ``random.choice``;
+        what is left is spread breadth-first from the emptiest cores."""
+        ctx = self._context(circuit, multicore_arch)
+        net = multicore_arch.network
+        cap = multicore_arch.qpu_qubit_num
+        nodes = list(net.nodes())
+        idx, D = ctx.arch.index, ctx.arch.D
+
+        def by_distance(n):  # neighbours of n, nearest first (BFS_placer.py:7-18); stable for ties
+            nb = list(net.neighbors(n))
+            nb.sort(key=lambda m: D[idx[n], idx[m]])
+            return nb
+
+        result = []
+        for layer in self.break_into_timeslices(circuit):
+            for n in nodes:
+                net.nodes[n]["qpu"].available_qubits = cap
+            room = {n: cap for n in nodes}
+            row = {}
+            members = set()
+            for cmd in layer:
+                members.update(cmd.qubits)
+            members = list(members)
+            done = set()
+            for cmd in layer:
+                qs = cmd.qubits
+                if len(qs) == 2:
+                    a, b = qs
+                    if a in done or b in done:
+                        continue
+                    home = next((n for n in nodes if room[n] >= 2), None)
+                    if home is not None:
+                        row[a] = row[b] = home
+                        room[home] -= 2
+                        done.update((a, b))
+                    else:
+                        pairs = [(n1, n2, D[idx[n1], idx[n2]]) for n1 in nodes if room[n1] >= 1
+                                 for n2 in by_distance(n1) if room[n2] >= 1]
+                        pairs.sort(key=lambda x: x[2])
+                        for n1, n2, _ in pairs:
+                            if room[n1] >= 1 and room[n2] >= 1:
+                                row[a], row[b] = n1, n2
+                                room[n1] -= 1
+                                room[n2] -= 1
+                                done.update((a, b))
+                                break
+                if len(qs) == 1:
+                    q = qs[0]
+                    if q not in done:
+                        open_nodes = [n for n in nodes if room[n] > 0]
+                        if open_nodes:
+                            n = random.choice(open_nodes)
+                            row[q] = n
+                            room[n] -= 1
+                            done.add(q)
+            waiting = [q for q in members if q not in done]
+            start = [(n, room[n]) for n in nodes if room[n] > 0]
+            start.sort(key=lambda x: x[1], reverse=True)
+            queue = deque(n for n, _ in start)
+            seen = set(queue)
+            while queue and waiting:
+                n = queue.popleft()
+                row[waiting.pop(0)] = n
+                room[n] -= 1
+                for m in by_distance(n):
+                    if m not in seen and room[m] > 0:
+                        seen.add(m)
+                        queue.append(m)
+            result.append(row)
+        return result
+
+
+PLACERS = {"HQA": hqa_placer, "TRHQA": trhqa_placer, "GTRHQA": gtrhqa_placer, "RANDOM": random_placer,
+           "BFS": bfs_placer}

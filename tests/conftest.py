@@ -85,3 +85,38 @@ def golden_case(request):
 @pytest.fixture(params=SMALL_CASES)
 def small_case(request):
     return load_case(request.param)
+
+
+def case_circuit(gc):
+    """A Circuit object equivalent to the fixture's gate tables (names are irrelevant to placers)."""
+    from quantum_simulator_amd.circuit import Circuit, OpType
+    circ = Circuit()
+    regs = {}
+    for s in gc.meta["qubits"]:
+        reg, idx = s[:-1].split("[")
+        regs[reg] = max(regs.get(reg, 0), int(idx) + 1)
+    for reg, n in regs.items():
+        circ.add_q_register(reg, n)
+    qs = circ.qubits
+    assert [str(q) for q in qs] == gc.meta["qubits"]
+    for g, mr in zip(gc.gate_q, gc.gate_mr):
+        if mr:
+            circ.add_command("measure", [qs[i] for i in g], optype=OpType.Measure)
+        else:
+            circ.add_command("cx" if len(g) == 2 else "x", [qs[i] for i in g])
+    return circ
+
+
+def case_arch(gc):
+    """The fixture's architecture rebuilt the way the reference's driver builds it: seed the global
+    RNG, construct; the edge weights must come out as recorded."""
+    import random
+    from quantum_simulator_amd.multicore import multicore, graph_tables
+    m = gc.meta
+    random.seed(m["arch_seed"])
+    arch = multicore(m["nx"], m["ny"], ncm_qubits=4, ncp_qubits=m["cap"],
+                     edge_weight_range=tuple(m["weight_range"]), network_type=m["topology"])
+    nodes, eu, ev, w = graph_tables(arch.network)
+    assert [float(x).hex() for x in w] == m["edge_w_hex"]
+    assert [(int(a), int(b)) for a, b in zip(eu, ev)] == [(e[0], e[1]) for e in gc.edges]
+    return arch
