@@ -165,6 +165,69 @@ int qp_cost_matrix(int32_t kind, const QpCircuit* circ, const QpDTable* dt, int6
                    int32_t max_ops, const uint8_t* avail, const int32_t* n_avail, double* cost_out,
                    void* stream);
 
+/* ---------------------------------------------------------------- device: QUBO placer */
+
+/* The QUBO placer's objective (Qubo_placer.py:84-133) over binary variables x[t,j,i] (active qubit i
+ * of slice t on core j) and slack bits y[t,j,p], written as
+ *     E(s) = constant + sum_v linear[v] s_v + sum_{v<w} S[v][w] s_v s_w,
+ * all integers.  Variable order inside slice t: v = off[t] + j*(n_t+cap) + k, k < n_t for x, else y;
+ * every slice is padded to a multiple of 128 variables (padding variables are always 0).
+ * S is block-tridiagonal over slices and is passed as int8 "segments": for the rows of slice t, each
+ * segment is a dense row-major matrix [rows of slice t][K columns] multiplying the K variables that
+ * start at xoff; segments of one slice are summed (a coupling larger than 127 is split into layers). */
+typedef struct QpQuboSeg {
+    const int8_t* mat; /* dev */
+    int32_t ld;        /* row pitch in bytes */
+    int32_t K;         /* columns, multiple of 64 */
+    int64_t xoff;      /* first variable (padded axis) the columns refer to */
+} QpQuboSeg;
+
+typedef struct QpQuboDense {
+    int32_t T;
+    int32_t Npad;              /* padded variable count, multiple of 128 */
+    int32_t constant;
+    int32_t pad_;
+    const QpQuboSeg* segs;     /* dev */
+    const int32_t* seg_ptr;    /* dev [T+1]: segments of slice t are segs[seg_ptr[t] .. seg_ptr[t+1]) */
+    const int32_t* tile_slice; /* dev [Npad/128]: slice of each 128-variable tile */
+    const int64_t* off;        /* dev [T+1]: padded variable offset of each slice */
+    const int32_t* linear;     /* dev [Npad] */
+} QpQuboDense;
+
+/* Structure of the same model for the annealer (all pointers dev; per-(slice, qubit) tables have row
+ * pitch nmax = max_t n_t). */
+typedef struct QpQuboStruct {
+    int32_t T, C, cap, nmax;
+    int64_t Npad;
+    const int32_t* n;       /* [T] active qubits per slice */
+    const int64_t* off;     /* [T+1] */
+    const uint8_t* deg;     /* [T*nmax] interaction-graph degree */
+    const int32_t* nbr_ptr; /* [T*nmax+1] CSR over interaction partners (local indices of the slice) */
+    const int16_t* nbr;
+    const int16_t* nxt;     /* [T*nmax] index of the same qubit in slice t+1, -1 if inactive there */
+    const int16_t* prv;     /* [T*nmax] same for slice t-1 */
+    const uint8_t* hops;    /* [C*C] hop counts */
+} QpQuboStruct;
+
+/* Local fields F[v][r] = sum_w S[v][w] s_w of R replica states (int8 0/1, stored replica-major:
+ * Xt[r][v], r < R, v < Npad; R a multiple of 128) by int8 MFMA.  F: dev int32 [Npad][R].
+ * The energy change of flipping v in replica r is (1 - 2 s_v)(linear[v] + F[v][r]). */
+int qp_qubo_fields_i32(const QpQuboDense* model, const int8_t* Xt, int32_t R, int32_t* F, void* stream);
+
+/* Exact energies energy[r] = E(state r) of R replica states, same contraction with the reduction
+ * sum_v s_v (2 linear[v] + F[v][r]) fused into its epilogue (integer atomics: order-independent).
+ * This is the number pyqubo's decoded sample reports as .energy (Qubo_placer.py:141-142). */
+int qp_qubo_energy_i32(const QpQuboDense* model, const int8_t* Xt, int32_t R, int32_t* energy, void* stream);
+
+/* Replica-parallel simulated annealing (stands in for neal.SimulatedAnnealingSampler().sample,
+ * Qubo_placer.py:139-140; R plays num_reads).  Metropolis sweeps over all variables with a geometric
+ * inverse-temperature schedule beta_hot -> beta_cold.  Xt: dev int8 [R][Npad], final states on return
+ * (initial states on entry when QP_QUBO_INIT_GIVEN, else random).  dE_out[r]: summed energy change of
+ * the accepted flips of replica r.  Deterministic for a given seed. */
+#define QP_QUBO_INIT_GIVEN 1
+int qp_qubo_anneal(const QpQuboStruct* model, int32_t R, int32_t sweeps, double beta_hot, double beta_cold,
+                   uint64_t seed, int8_t* Xt, int32_t* dE_out, int32_t flags, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

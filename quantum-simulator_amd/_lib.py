@@ -26,6 +26,25 @@ class QpDTable(C.Structure):
     _fields_ = [("kind", C.c_int32), ("C", C.c_int32), ("table", C.c_void_p)]
 
 
+class QpQuboSeg(C.Structure):
+    _fields_ = [("mat", C.c_void_p), ("ld", C.c_int32), ("K", C.c_int32), ("xoff", C.c_int64)]
+
+
+class QpQuboDense(C.Structure):
+    _fields_ = [("T", C.c_int32), ("Npad", C.c_int32), ("constant", C.c_int32), ("pad_", C.c_int32),
+                ("segs", C.c_void_p), ("seg_ptr", C.c_void_p), ("tile_slice", C.c_void_p), ("off", C.c_void_p),
+                ("linear", C.c_void_p)]
+
+
+class QpQuboStruct(C.Structure):
+    _fields_ = [("T", C.c_int32), ("C", C.c_int32), ("cap", C.c_int32), ("nmax", C.c_int32), ("Npad", C.c_int64),
+                ("n", C.c_void_p), ("off", C.c_void_p), ("deg", C.c_void_p), ("nbr_ptr", C.c_void_p),
+                ("nbr", C.c_void_p), ("nxt", C.c_void_p), ("prv", C.c_void_p), ("hops", C.c_void_p)]
+
+
+QP_QUBO_INIT_GIVEN = 1
+
+
 class QplaceError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"libqplace error {code}: {msg}")
@@ -50,6 +69,10 @@ EXPORTS = {
     "qp_cost_matrix": (C.c_int, [C.c_int32, C.POINTER(QpCircuit), C.POINTER(QpDTable), C.c_int64, C.c_void_p,
                                  C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p]),
+    "qp_qubo_fields_i32": (C.c_int, [C.POINTER(QpQuboDense), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "qp_qubo_energy_i32": (C.c_int, [C.POINTER(QpQuboDense), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "qp_qubo_anneal": (C.c_int, [C.POINTER(QpQuboStruct), C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_uint64,
+                                 C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
 }
 
 _lib = None

@@ -1,0 +1,410 @@
+// QUBO placer on gfx950: exact integer energies / local fields of R replica states by an int8 MFMA
+// contraction against the block-tridiagonal coefficient matrix, and replica-parallel simulated
+// annealing that works from the model's structure (no coefficient matrix) with one wave per replica.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+
+#include "qplace_internal.h"
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return qp::fail(QP_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------------------------------------
+// F = S . X  (and  sum_v x_v (2 a_v + F_v))  with v_mfma_i32_32x32x32_i8
+//
+// Workgroup = 4 waves (2 x 2), tile = 128 variables x 128 replicas, each wave 64 x 64 as 2 x 2 MFMA
+// tiles.  Both operands are contiguous along the contraction axis (S row-major, states stored
+// replica-major), so a lane's A or B fragment is 16 consecutive bytes.  Tiles go through LDS with an
+// 80-byte row pitch: 16 consecutive rows then start in 16 different 16-byte slots of the 256-byte
+// bank row, which is what ds_read_b128 needs to run conflict-free.
+// ------------------------------------------------------------------------------------------------
+
+constexpr int kTile = 128;
+constexpr int kBK = 64;
+constexpr int kPitch = 80;
+
+struct GemmArgs {
+    const QpQuboSeg* segs;
+    const int32_t* seg_ptr;     // [T+1]
+    const int32_t* tile_slice;  // [row tiles]
+    const int64_t* off;         // [T+1] padded variable offset of each slice
+    const int8_t* Xt;           // [R][Npad]
+    const int32_t* linear;      // [Npad]
+    int32_t* out;               // fields: [Npad][R]; energy: [R] (accumulated with integer atomics)
+    int32_t Npad, R;
+};
+
+template <bool ENERGY>
+__global__ __launch_bounds__(256) void k_qubo_gemm(GemmArgs p) {
+    __shared__ __align__(16) int8_t sA[kTile * kPitch];
+    __shared__ __align__(16) int8_t sB[kTile * kPitch];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int rowtile = blockIdx.x, coltile = blockIdx.y;
+    const int t = p.tile_slice[rowtile];
+    const int64_t v0 = (int64_t)rowtile * kTile;     // first variable (padded axis) of this tile
+    const int64_t vrow = v0 - p.off[t];              // row inside the slice's blocks
+    const int r0 = coltile * kTile;
+
+    v16i acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[a][b][k] = 0;
+
+    // staging: thread -> (row = tid / 4 [+64], 16-byte piece = tid % 4) of a 128 x 64 byte tile
+    const int srow = tid >> 2, spiece = tid & 3;
+    for (int sg = p.seg_ptr[t]; sg < p.seg_ptr[t + 1]; ++sg) {
+        const QpQuboSeg seg = p.segs[sg];
+        const int8_t* Ab = seg.mat + (size_t)vrow * seg.ld;
+        const int8_t* Bb = p.Xt + (size_t)r0 * p.Npad + seg.xoff;
+        for (int k0 = 0; k0 < seg.K; k0 += kBK) {
+            const uint4 a0 = *reinterpret_cast<const uint4*>(Ab + (size_t)srow * seg.ld + k0 + spiece * 16);
+            const uint4 a1 = *reinterpret_cast<const uint4*>(Ab + (size_t)(srow + 64) * seg.ld + k0 + spiece * 16);
+            const uint4 b0 = *reinterpret_cast<const uint4*>(Bb + (size_t)srow * p.Npad + k0 + spiece * 16);
+            const uint4 b1 = *reinterpret_cast<const uint4*>(Bb + (size_t)(srow + 64) * p.Npad + k0 + spiece * 16);
+            __syncthreads();
+            *reinterpret_cast<uint4*>(sA + srow * kPitch + spiece * 16) = a0;
+            *reinterpret_cast<uint4*>(sA + (srow + 64) * kPitch + spiece * 16) = a1;
+            *reinterpret_cast<uint4*>(sB + srow * kPitch + spiece * 16) = b0;
+            *reinterpret_cast<uint4*>(sB + (srow + 64) * kPitch + spiece * 16) = b1;
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < kBK / 32; ++kk) {
+                v4i fa[2], fb[2];
+                const int koff = kk * 32 + (lane >> 5) * 16;
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+                    fa[a] = *reinterpret_cast<const v4i*>(sA + (wm * 64 + a * 32 + (lane & 31)) * kPitch + koff);
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    fb[b] = *reinterpret_cast<const v4i*>(sB + (wn * 64 + b * 32 + (lane & 31)) * kPitch + koff);
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[a], fb[b], acc[a][b], 0, 0, 0);
+            }
+        }
+    }
+
+    // accumulator element k of lane l: row (k & 3) + 8 * (k >> 2) + 4 * (l >> 5), column l & 31
+    const int h = lane >> 5;
+    if constexpr (!ENERGY) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int col = r0 + wn * 64 + b * 32 + (lane & 31);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int64_t row = v0 + wm * 64 + a * 32 + (k & 3) + 8 * (k >> 2) + 4 * h;
+                    p.out[(size_t)row * p.R + col] = acc[a][b][k];
+                }
+            }
+    } else {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int col = r0 + wn * 64 + b * 32 + (lane & 31);
+            int s = 0;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int64_t row = v0 + wm * 64 + a * 32 + 8 * g + 4 * h;
+                    const uint32_t x4 = *reinterpret_cast<const uint32_t*>(p.Xt + (size_t)col * p.Npad + row);
+                    const int4 lin = *reinterpret_cast<const int4*>(p.linear + row);
+                    const int l4[4] = {lin.x, lin.y, lin.z, lin.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if ((x4 >> (8 * j)) & 1u) s += 2 * l4[j] + acc[a][b][4 * g + j];
+                }
+            s += __shfl_xor(s, 32, 64);
+            if (h == 0) atomicAdd(&p.out[col], s);
+        }
+    }
+}
+
+// energy2[r] -> constant + energy2[r] / 2
+__global__ void k_qubo_finish(int32_t* e, int32_t R, int32_t constant) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < R) e[r] = constant + e[r] / 2;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Simulated annealing, one wave per replica.
+//
+// Lane (s, j) owns core j of one timeslice; 64 / C slices of equal parity are updated at once
+// (slices two apart never share a term).  Inside a slice the lanes walk a Latin square: in step k lane
+// j proposes qubit i = m*C + (k - j mod C), so the proposals of one step touch distinct qubits and
+// distinct cores and therefore share no term either — simultaneous Metropolis updates of them equal
+// sequential ones.  Per replica the wave keeps, in LDS, one core bit-mask per (slice, active qubit);
+// core loads and slack bits live in registers while their lane owns the core.
+// ------------------------------------------------------------------------------------------------
+
+struct SaArgs {
+    QpQuboStruct m;
+    int8_t* Xt;
+    int32_t* dE;
+    int32_t R, sweeps, flags;
+    float beta_hot, beta_ratio_log;  // beta(s) = hot * exp(ratio_log * s / (sweeps - 1))
+    uint64_t seed;
+};
+
+__device__ inline uint32_t rng_next(uint32_t& s) {
+    s ^= s << 13;
+    s ^= s >> 17;
+    s ^= s << 5;
+    return s;
+}
+
+__device__ inline uint32_t mix32(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (uint32_t)(z ^ (z >> 32)) | 1u;
+}
+
+__device__ inline bool metropolis(int dE, float beta, uint32_t& rng) {
+    if (dE <= 0) return true;
+    const float u = (float)(rng_next(rng) >> 8) * (1.0f / 16777216.0f);
+    return u < __expf(-beta * (float)dE);
+}
+
+__global__ __launch_bounds__(256) void k_qubo_anneal(SaArgs p) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    const QpQuboStruct& m = p.m;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (r >= p.R) return;
+    const int T = m.T, C = m.C, cap = m.cap, nmax = m.nmax;
+    // per-wave LDS: mask[T][nmax] u32, load[T][C] i32, slack[T][C] u32
+    const size_t per_wave = ((size_t)T * nmax + 2 * (size_t)T * C) * 4;
+    uint32_t* mask = reinterpret_cast<uint32_t*>(smem + wave * per_wave);
+    int32_t* load = reinterpret_cast<int32_t*>(mask + (size_t)T * nmax);
+    uint32_t* slack = reinterpret_cast<uint32_t*>(load + (size_t)T * C);
+    int8_t* X = p.Xt + (size_t)r * m.Npad;
+    uint32_t rng = mix32(p.seed * 0x100000001B3ull + ((uint64_t)r << 8) + lane);
+    const uint32_t capmask = cap >= 32 ? 0xFFFFFFFFu : ((1u << cap) - 1u);
+    const uint32_t coremask = C >= 32 ? 0xFFFFFFFFu : ((1u << C) - 1u);
+
+    // ---- initial state
+    for (int t = 0; t < T; ++t) {
+        const int n = m.n[t];
+        const int W = n + cap;
+        const int8_t* Xs = X + m.off[t];
+        for (int i = lane; i < nmax; i += 64) {
+            uint32_t bits = 0;
+            if (i < n) {
+                if (p.flags & QP_QUBO_INIT_GIVEN) {
+                    for (int j = 0; j < C; ++j) bits |= (uint32_t)(Xs[(size_t)j * W + i] & 1) << j;
+                } else {
+                    bits = rng_next(rng) & coremask;
+                }
+            }
+            mask[t * nmax + i] = bits;
+        }
+        for (int j = lane; j < C; j += 64) {
+            uint32_t y = 0;
+            if (p.flags & QP_QUBO_INIT_GIVEN) {
+                for (int q = 0; q < cap; ++q) y |= (uint32_t)(Xs[(size_t)j * W + n + q] & 1) << q;
+            } else {
+                y = rng_next(rng) & capmask;
+            }
+            slack[t * C + j] = y;
+        }
+    }
+    for (int t = 0; t < T; ++t) {
+        const int n = m.n[t];
+        for (int j = lane; j < C; j += 64) {
+            int L = -__popc(slack[t * C + j]);
+            for (int i = 0; i < n; ++i) L += (mask[t * nmax + i] >> j) & 1u;
+            load[t * C + j] = L;
+        }
+    }
+
+    // ---- sweeps
+    const int S = C <= 64 ? max(1, 64 / C) : 1;  // slices updated side by side
+    const int ls = lane / C, lj = lane - ls * C;
+    const bool lane_used = ls < S;
+    int dEsum = 0;
+    for (int sweep = 0; sweep < p.sweeps; ++sweep) {
+        const float beta = p.beta_hot * __expf(p.beta_ratio_log * (p.sweeps > 1 ? (float)sweep / (float)(p.sweeps - 1) : 0.0f));
+        for (int par = 0; par < 2; ++par) {
+            const int nsl = (T - par + 1) / 2;  // slices of this parity
+            for (int b0 = 0; b0 < nsl; b0 += S) {
+                const int k = b0 + ls;
+                const int t = par + 2 * k;
+                const bool on = lane_used && k < nsl;
+                const int n = on ? m.n[t] : 0;
+                int nb = n;  // widest slice of the batch
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) nb = max(nb, __shfl_xor(nb, o, 64));
+                int L = on ? load[t * C + lj] : 0;
+                uint32_t y = on ? slack[t * C + lj] : 0u;
+                uint32_t* mk = mask + (size_t)(on ? t : 0) * nmax;
+                const size_t tb = (size_t)(on ? t : 0) * nmax;
+                const int blocks = (nb + C - 1) / C;
+                for (int mb = 0; mb < blocks; ++mb) {
+                    for (int step = 0; step < C; ++step) {
+                        int rel = step - lj;
+                        if (rel < 0) rel += C;
+                        const int i = mb * C + rel;
+                        if (on && i < n) {
+                            const uint32_t w = mk[i];
+                            const int bit = (w >> lj) & 1u;
+                            const int d = 1 - 2 * bit;
+                            const int Ai = __popc(w);
+                            int lap = m.deg[tb + i];
+                            for (int e = m.nbr_ptr[tb + i]; e < m.nbr_ptr[tb + i + 1]; ++e)
+                                lap -= 2 * (int)((mk[m.nbr[e]] >> lj) & 1u);
+                            int mv = 0;
+                            const int ix = m.nxt[tb + i], ip = m.prv[tb + i];
+                            if (ix >= 0) {
+                                uint32_t o = mask[(size_t)(t + 1) * nmax + ix];
+                                while (o) {
+                                    const int l = __ffs(o) - 1;
+                                    o &= o - 1;
+                                    mv += m.hops[lj * C + l];
+                                }
+                            }
+                            if (ip >= 0) {
+                                uint32_t o = mask[(size_t)(t - 1) * nmax + ip];
+                                while (o) {
+                                    const int l = __ffs(o) - 1;
+                                    o &= o - 1;
+                                    mv += m.hops[l * C + lj];
+                                }
+                            }
+                            const int dE = 4 * d * (2 * (Ai - 1) + d) + 4 * d * (2 * L + d) + 10 * d * (lap + mv);
+                            if (metropolis(dE, beta, rng)) {
+                                mk[i] = w ^ (1u << lj);
+                                L += d;
+                                dEsum += dE;
+                            }
+                        }
+                    }
+                }
+                if (on) {
+                    for (int q = 0; q < cap; ++q) {
+                        const int bit = (y >> q) & 1u;
+                        const int d = 1 - 2 * bit;
+                        const int dE = 4 * d * (-2 * L + d);
+                        if (metropolis(dE, beta, rng)) {
+                            y ^= 1u << q;
+                            L -= d;
+                            dEsum += dE;
+                        }
+                    }
+                    load[t * C + lj] = L;
+                    slack[t * C + lj] = y;
+                }
+            }
+        }
+    }
+
+    // ---- write the state back (padding bytes are zeroed) and the summed energy change
+    for (int t = 0; t < T; ++t) {
+        const int n = m.n[t];
+        const int W = n + cap;
+        int8_t* Xs = X + m.off[t];
+        const int64_t total = m.off[t + 1] - m.off[t];
+        for (int64_t v = lane; v < total; v += 64) {
+            int8_t val = 0;
+            if (v < (int64_t)C * W) {
+                const int j = (int)(v / W), kx = (int)(v - (int64_t)j * W);
+                val = kx < n ? (int8_t)((mask[t * nmax + kx] >> j) & 1u) : (int8_t)((slack[t * C + j] >> (kx - n)) & 1u);
+            }
+            Xs[v] = val;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dEsum += __shfl_xor(dEsum, o, 64);
+    if (lane == 0) p.dE[r] = dEsum;
+}
+
+int check_dense(const char* fn, const QpQuboDense* m, const int8_t* Xt, int32_t R, const void* out) {
+    if (!m || !Xt || !out) return qp::fail(QP_EINVAL, "%s: null argument", fn);
+    if (m->T <= 0 || m->Npad <= 0 || m->Npad % kTile) return qp::fail(QP_EINVAL, "%s: Npad must be a positive multiple of 128", fn);
+    if (R <= 0 || R % kTile) return qp::fail(QP_EINVAL, "%s: R must be a positive multiple of 128", fn);
+    if (!m->segs || !m->seg_ptr || !m->tile_slice || !m->off || !m->linear) return qp::fail(QP_EINVAL, "%s: model tables missing", fn);
+    return QP_OK;
+}
+
+GemmArgs gemm_args(const QpQuboDense* m, const int8_t* Xt, int32_t R, int32_t* out) {
+    GemmArgs a{};
+    a.segs = m->segs;
+    a.seg_ptr = m->seg_ptr;
+    a.tile_slice = m->tile_slice;
+    a.off = m->off;
+    a.Xt = Xt;
+    a.linear = m->linear;
+    a.out = out;
+    a.Npad = m->Npad;
+    a.R = R;
+    return a;
+}
+
+}  // namespace
+
+extern "C" int qp_qubo_fields_i32(const QpQuboDense* m, const int8_t* Xt, int32_t R, int32_t* F, void* stream_) {
+    if (int rc = check_dense("qp_qubo_fields_i32", m, Xt, R, F)) return rc;
+    const dim3 grid(m->Npad / kTile, R / kTile);
+    k_qubo_gemm<false><<<grid, 256, 0, static_cast<hipStream_t>(stream_)>>>(gemm_args(m, Xt, R, F));
+    HIP_TRY(hipGetLastError());
+    return QP_OK;
+}
+
+extern "C" int qp_qubo_energy_i32(const QpQuboDense* m, const int8_t* Xt, int32_t R, int32_t* energy, void* stream_) {
+    if (int rc = check_dense("qp_qubo_energy_i32", m, Xt, R, energy)) return rc;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    HIP_TRY(hipMemsetAsync(energy, 0, (size_t)R * sizeof(int32_t), stream));
+    const dim3 grid(m->Npad / kTile, R / kTile);
+    k_qubo_gemm<true><<<grid, 256, 0, stream>>>(gemm_args(m, Xt, R, energy));
+    HIP_TRY(hipGetLastError());
+    k_qubo_finish<<<(R + 255) / 256, 256, 0, stream>>>(energy, R, m->constant);
+    HIP_TRY(hipGetLastError());
+    return QP_OK;
+}
+
+extern "C" int qp_qubo_anneal(const QpQuboStruct* m, int32_t R, int32_t sweeps, double beta_hot, double beta_cold,
+                              uint64_t seed, int8_t* Xt, int32_t* dE_out, int32_t flags, void* stream_) {
+    if (!m || !Xt || !dE_out) return qp::fail(QP_EINVAL, "qp_qubo_anneal: null argument");
+    if (m->T <= 0 || m->C <= 0 || m->C > 32 || m->cap <= 0 || m->cap > 32 || m->nmax <= 0)
+        return qp::fail(QP_EINVAL, "qp_qubo_anneal: needs 1..32 cores and capacity 1..32");
+    if (R <= 0 || sweeps < 0 || !(beta_hot > 0) || !(beta_cold > 0)) return qp::fail(QP_EINVAL, "qp_qubo_anneal: bad R/sweeps/beta");
+    if (!m->n || !m->off || !m->deg || !m->nbr_ptr || !m->nxt || !m->prv || !m->hops)
+        return qp::fail(QP_EINVAL, "qp_qubo_anneal: model tables missing");
+    const size_t per_wave = ((size_t)m->T * m->nmax + 2 * (size_t)m->T * m->C) * 4;
+    int waves = 4;
+    while (waves > 1 && per_wave * waves > 64 * 1024) waves >>= 1;
+    if (per_wave * waves > 160 * 1024) return qp::fail(QP_EINVAL, "qp_qubo_anneal: model too large for LDS (%zu bytes per replica)", per_wave);
+    SaArgs a{};
+    a.m = *m;
+    a.Xt = Xt;
+    a.dE = dE_out;
+    a.R = R;
+    a.sweeps = sweeps;
+    a.flags = flags;
+    a.beta_hot = (float)beta_hot;
+    a.beta_ratio_log = (float)std::log(beta_cold / beta_hot);
+    a.seed = seed;
+    const size_t lds = per_wave * waves;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_qubo_anneal), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    k_qubo_anneal<<<(R + waves - 1) / waves, waves * 64, lds, static_cast<hipStream_t>(stream_)>>>(a);
+    HIP_TRY(hipGetLastError());
+    return QP_OK;
+}

@@ -1,0 +1,271 @@
+"""Config-file driver: the reference's ``python main.py --config file`` flow (main.py:16-165) on this
+package's placers, with the work optionally sharded over the ranks of a torch.distributed job.
+
+Config format and required keys are the reference's (config_parser.py:20-84): ``key = value`` lines,
+``#`` comments; keys mode, topology, num_cores_x, num_cores_y, ncm_qubits, ncp_qubits,
+edge_weight_range, circuit_folders, placers, repeats, out_csv, plot_file.  Optional additions:
+``seed`` (seeds Python's global ``random`` once before the architecture is built; the reference never
+seeds, so its runs are not reproducible) and ``device``.
+
+Output: the same CSV (``file, <P>_time_mean, <P>_cost_mean`` per placer, means over finite repeats,
+main.py:103-104,117-130).  A repeat that raises records inf, as in main.py:99-102.
+
+Sharding: the units (file, placer, repeat) are dealt round-robin to ranks; each rank keeps per
+(file, placer) the sums [finite cost sum, finite count, time sum, time count] and the minimum cost,
+and one all-reduce (SUM) plus one (MIN) at the end gives every rank the full table.  With more than
+one rank the RNG-driven placers (RANDOM, BFS) seed ``random`` per unit from (seed, file, placer,
+repeat), because one shared stream cannot be split; deterministic placers are unaffected.
+"""
+from __future__ import annotations
+
+import csv
+import math
+import os
+import random
+import time
+import zlib
+
+import numpy as np
+
+TOPOLOGY_NAMES = ["mesh", "line", "star", "tree", "torus", "complete"]
+REQUIRED = ["mode", "topology", "num_cores_x", "num_cores_y", "ncm_qubits", "ncp_qubits", "edge_weight_range",
+            "circuit_folders", "placers", "repeats", "out_csv", "plot_file"]
+
+
+def _value(text: str):
+    v = text.strip()
+    try:
+        return int(v)
+    except ValueError:
+        pass
+    if "," in v:
+        parts = [p.strip() for p in v.split(",") if p.strip()]
+        try:
+            nums = [float(p) for p in parts]
+            return nums if len(nums) > 1 else nums[0]
+        except ValueError:
+            return parts
+    return v
+
+
+def parse_config_file(path: str) -> dict:
+    assert os.path.exists(path), f"Config file not found: {path}"
+    cfg = {}
+    with open(path) as f:
+        for line in f:
+            line = line.strip()
+            if not line or line.startswith("#") or "=" not in line:
+                continue
+            k, v = line.split("=", 1)
+            cfg[k.strip()] = _value(v)
+    for key in REQUIRED[:2]:
+        assert key in cfg, f"Missing required parameter: {key}"
+    assert cfg["mode"] in ["simulate"], "mode must be 'simulate' or ..."
+    assert cfg["topology"] in TOPOLOGY_NAMES, "Invalid topology, must be one of mesh, line, star, tree, torus, complete"
+    for key in REQUIRED[2:]:
+        assert key in cfg, f"Missing required parameter: {key}"
+    ewr = cfg["edge_weight_range"]
+    if isinstance(ewr, list) and len(ewr) >= 2:
+        cfg["edge_weight_range"] = (float(ewr[0]), float(ewr[1]))
+    else:
+        raise AssertionError("edge_weight_range must be two numbers separated by a comma, e.g. 1.0,10.0")
+    cf = cfg["circuit_folders"]
+    folders = cf if isinstance(cf, list) else [p.strip() for p in str(cf).split(",") if p.strip()]
+    cfg["circuit_folders"] = [os.path.expanduser(p) for p in folders]
+    pl = cfg["placers"]
+    cfg["placers"] = [str(p).strip() for p in pl] if isinstance(pl, list) else [p.strip() for p in str(pl).split(",") if p.strip()]
+    return cfg
+
+
+def build_arch(cfg):
+    """main.py:50-61, including its fall-back: any constructor error (e.g. topology ``complete``, which
+    the parser accepts and the topology builder does not know) yields a 4x4 all-to-all machine with 16
+    qubits per core and weights in (1, 10)."""
+    from .multicore import multicore
+    try:
+        return multicore(int(cfg.get("num_cores_x", 8)), int(cfg.get("num_cores_y", 8)),
+                         ncm_qubits=int(cfg.get("ncm_qubits", 4)), ncp_qubits=int(cfg.get("ncp_qubits", 2)),
+                         edge_weight_range=tuple(cfg.get("edge_weight_range", (1.0, 3.0))),
+                         network_type=cfg.get("topology", "all_to_all"))
+    except Exception as exc:  # noqa: BLE001 - mirrors the reference's blanket fall-back
+        print("Warning: multicore init failed with args, falling back to default ctor:", exc)
+        return multicore(4, 4)
+
+
+def list_qasm(folders):
+    out = []
+    for folder in folders:
+        if not os.path.exists(folder):
+            print(f"Warning: circuit folder not found: {folder}")
+            continue
+        for fn in sorted(os.listdir(folder)):
+            if fn.lower().endswith(".qasm"):
+                out.append(os.path.join(folder, fn))
+    if not out:
+        raise RuntimeError("No .qasm files found in circuit_folders.")
+    return out
+
+
+def _dist():
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist
+    except ImportError:
+        pass
+    return None
+
+
+def reduce_table(local: np.ndarray, local_min: np.ndarray, device=None):
+    """All-reduce the per-(file, placer) sums (SUM) and minima (MIN) over the job's ranks; identity
+    when not distributed.  Arrays are float64; the payload is a few hundred bytes."""
+    dist = _dist()
+    if dist is None or dist.get_world_size() == 1:
+        return local, local_min
+    import torch
+    dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
+    s = torch.from_numpy(np.ascontiguousarray(local)).to(dev)
+    m = torch.from_numpy(np.ascontiguousarray(local_min)).to(dev)
+    dist.all_reduce(s, op=dist.ReduceOp.SUM)
+    dist.all_reduce(m, op=dist.ReduceOp.MIN)
+    return s.cpu().numpy(), m.cpu().numpy()
+
+
+def run_simulation(cfg, device=None, verbose=True):
+    from .circuit import circuit_from_qasm
+    from .placers import PLACERS
+
+    dist = _dist()
+    rank = dist.get_rank() if dist else 0
+    world = dist.get_world_size() if dist else 1
+    repeats = int(cfg["repeats"])
+    names = [p for p in cfg["placers"]]
+    seed = cfg.get("seed")
+    if seed is not None:
+        random.seed(int(seed))
+    arch = build_arch(cfg)
+    files = list_qasm(cfg["circuit_folders"])
+    placers = {n: PLACERS[n](device) for n in names if n in PLACERS}
+    for n in names:
+        if n not in placers and verbose and rank == 0:
+            print(f"Placer '{n}' not recognized, skipping.")
+
+    # [cost sum, cost count, time sum, time count] per (file, placer)
+    sums = np.zeros((len(files), len(names), 4))
+    mins = np.full((len(files), len(names)), np.inf)
+    unit = 0
+    for fi, path in enumerate(files):
+        circuit = None
+        for pi, name in enumerate(names):
+            if name not in placers:
+                continue
+            for rep in range(repeats):
+                mine = unit % world == rank
+                unit += 1
+                if not mine:
+                    continue
+                if circuit is None:
+                    circuit = circuit_from_qasm(path, maxwidth=1024)
+                if world > 1 and name in ("RANDOM", "BFS"):
+                    random.seed(zlib.crc32(f"{seed}|{path}|{name}|{rep}".encode()))
+                try:
+                    t0 = time.perf_counter()
+                    part = placers[name].place_per_timeslice(circuit, arch)
+                    dt = time.perf_counter() - t0
+                    cost = float(placers[name].per_timeslice_cost(circuit, part, arch))
+                except Exception as exc:  # noqa: BLE001 - main.py:99-102
+                    if verbose:
+                        print(f"[{name}] run failed: {exc}")
+                    dt, cost = math.inf, math.inf
+                if math.isfinite(cost):
+                    sums[fi, pi, 0] += cost
+                    sums[fi, pi, 1] += 1
+                    mins[fi, pi] = min(mins[fi, pi], cost)
+                if math.isfinite(dt):
+                    sums[fi, pi, 2] += dt
+                    sums[fi, pi, 3] += 1
+    sums, mins = reduce_table(sums, mins, device)
+
+    results = []
+    for fi, path in enumerate(files):
+        entry = {"file": path}
+        for pi, name in enumerate(names):
+            if name not in placers:
+                continue
+            cs, cn, ts, tn = sums[fi, pi]
+            entry[f"{name}_time_mean"] = float(ts / tn) if tn else math.inf
+            entry[f"{name}_cost_mean"] = float(cs / cn) if cn else math.inf
+            entry[f"{name}_cost_min"] = float(mins[fi, pi])
+        results.append(entry)
+    if rank == 0:
+        write_csv(cfg["out_csv"], names, results)
+        if verbose:
+            print(f"\nWrote all results to {cfg['out_csv']}")
+        plot_results(cfg.get("plot_file"), names, results)
+    return results
+
+
+def write_csv(path, names, results):
+    cols = ["file"]
+    for n in names:
+        cols += [f"{n}_time_mean", f"{n}_cost_mean"]
+    with open(path, "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=cols, extrasaction="ignore")
+        w.writeheader()
+        for r in results:
+            w.writerow({c: r.get(c, math.inf) for c in cols})
+
+
+def plot_results(path, names, results):
+    """Grouped bars of mean runtime and mean cost per file (main.py:132-162); skipped without matplotlib."""
+    if not path:
+        return
+    try:
+        import matplotlib
+        matplotlib.use("Agg")
+        import matplotlib.pyplot as plt
+    except ImportError:
+        return
+    files = [r["file"] for r in results]
+    order = np.argsort(files)
+    x = np.arange(len(files))
+    width = 0.8 / max(1, len(names))
+    fig, axes = plt.subplots(1, 2, figsize=(14, 6))
+    for ax, key, title, ylabel in ((axes[0], "time_mean", "Average Runtime in s", "#time"),
+                                   (axes[1], "cost_mean", "Average Cost", "#expected intercore communication")):
+        for k, n in enumerate(names):
+            vals = [results[i].get(f"{n}_{key}", math.inf) for i in order]
+            ax.bar(x + (k - (len(names) - 1) / 2) * width, vals, width=width, label=n)
+        ax.set_title(title)
+        ax.set_xticks(x)
+        ax.set_xticklabels([files[i] for i in order], rotation=45, ha="right")
+        ax.set_ylabel(ylabel)
+        ax.legend()
+    fig.tight_layout()
+    fig.savefig(path, dpi=150, bbox_inches="tight")
+    plt.close(fig)
+
+
+def main(argv=None):
+    import argparse
+    ap = argparse.ArgumentParser(description="Placer comparison driver; run with --config <file>.")
+    ap.add_argument("--config", help="Path to text config file")
+    args = ap.parse_args(argv)
+    if not args.config:
+        print("No config file provided. Please run with --config <path_to_config_file>")
+        return
+    cfg = parse_config_file(args.config)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group("nccl")
+    if cfg.get("mode") == "simulate":
+        run_simulation(cfg)
+    else:
+        raise RuntimeError(f"Unknown mode in config: {cfg.get('mode')}")
+
+
+if __name__ == "__main__":
+    main()

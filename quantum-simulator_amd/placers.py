@@ -494,3 +494,53 @@ class bfs_placer(_SparsePlacer):
 
 PLACERS = {"HQA": hqa_placer, "TRHQA": trhqa_placer, "GTRHQA": gtrhqa_placer, "RANDOM": random_placer,
            "BFS": bfs_placer}
+
+
+class qubo_placer(_SparsePlacer):
+    """Qubo_placer.py:11-174 with the model built as integer tables, the sampler replaced by
+    replica-parallel annealing on the GPU (qp_qubo_anneal) and the lowest-energy replica chosen by
+    exact MFMA energies (qp_qubo_energy_i32).  ``num_reads`` and the seed default to the reference's
+    (10, 42); reads are rounded up to a multiple of 128 replicas, which costs nothing on the GPU.
+    The samples are not neal's (different generator and sweep order); energies are exact."""
+
+    def __init__(self, device=None, num_reads=10, num_sweeps=1000, seed=42):
+        super().__init__(device)
+        self.name = "QUBO"
+        self.num_reads, self.num_sweeps, self.seed = num_reads, num_sweeps, seed
+        self.last_energy = None
+
+    def _model(self, ctx, cap):
+        from .qubo import DeviceQubo, QuboModel
+        key = (id(ctx), cap)
+        if getattr(self, "_model_key", None) != key:
+            H = E.hops(ctx.arch.C, ctx.arch.eu, ctx.arch.ev)
+            self._qm = QuboModel(ctx.ir, ctx.arch.C, cap, H)
+            self._dq = DeviceQubo(self._qm, ctx.device)
+            self._model_key = key
+        return self._qm, self._dq
+
+    def place_per_timeslice(self, circuit, multicore_arch):
+        ctx = self._context(circuit, multicore_arch)
+        qm, dq = self._model(ctx, multicore_arch.qpu_qubit_num)
+        R = (max(1, self.num_reads) + 127) // 128 * 128
+        states, _ = dq.anneal(R, self.num_sweeps, seed=self.seed)
+        energy = dq.energy(states)
+        best = int(energy.argmin().item())
+        self.last_energy = int(energy[best].item())
+        rows = qm.decode(states[best].cpu().numpy())
+        qs, nodes = ctx.ir.qubits, ctx.arch.nodes
+        return [{qs[q]: nodes[c] for q, c in enumerate(row) if c is not None} for row in rows]
+
+    def per_timeslice_cost(self, circuit, partition, multicore_arch):
+        """Qubo_placer.py:177-207: the gate-ordered cost with unweighted hop counts."""
+        ctx = self._context(circuit, multicore_arch)
+        if len(partition) < ctx.ir.T:
+            raise IndexError("list index out of range")
+        arr = ctx.partition_array(partition, dense=False)
+        x = ctx.cost(arr, QP_V4, table=ctx.arch.hop_table)
+        if x == float("inf"):
+            raise KeyError("qubit missing from the partition where the cost function needs it")
+        return int(x)
+
+
+PLACERS["QUBO"] = qubo_placer

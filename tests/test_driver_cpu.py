@@ -1,0 +1,119 @@
+"""Host logic that needs no GPU: config parsing, CSV schema, and the cross-rank reduction of the
+driver exercised with two gloo ranks."""
+import math
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from quantum_simulator_amd import driver
+
+EXAMPLE = """\
+mode = simulate
+topology = mesh
+num_cores_x = 2
+num_cores_y = 1
+ncm_qubits = 4
+ncp_qubits = 130
+edge_weight_range = 1.0,2.0
+circuit_folders = circuits/gen
+placers = RANDOM, BFS, TRHQA, HQA, GTRHQA
+repeats = 3
+out_csv = results.csv
+plot_file = results_plot.png
+"""
+
+
+def test_parse_example_config(tmp_path):
+    p = tmp_path / "cfg.txt"
+    p.write_text(EXAMPLE + "# a comment\nseed = 7\n")
+    cfg = driver.parse_config_file(str(p))
+    assert cfg["topology"] == "mesh" and cfg["num_cores_x"] == 2 and cfg["ncp_qubits"] == 130
+    assert cfg["edge_weight_range"] == (1.0, 2.0)
+    assert cfg["circuit_folders"] == ["circuits/gen"]
+    assert cfg["placers"] == ["RANDOM", "BFS", "TRHQA", "HQA", "GTRHQA"]
+    assert cfg["repeats"] == 3 and cfg["seed"] == 7
+
+
+@pytest.mark.parametrize("drop", ["mode", "topology", "ncp_qubits", "placers", "out_csv"])
+def test_missing_key_is_an_assertion(tmp_path, drop):
+    p = tmp_path / "cfg.txt"
+    p.write_text("\n".join(l for l in EXAMPLE.splitlines() if not l.startswith(drop)))
+    with pytest.raises(AssertionError):
+        driver.parse_config_file(str(p))
+
+
+def test_bad_values(tmp_path):
+    p = tmp_path / "cfg.txt"
+    p.write_text(EXAMPLE.replace("topology = mesh", "topology = ring"))
+    with pytest.raises(AssertionError):
+        driver.parse_config_file(str(p))
+    p.write_text(EXAMPLE.replace("1.0,2.0", "5"))
+    with pytest.raises(AssertionError):
+        driver.parse_config_file(str(p))
+
+
+def test_complete_topology_falls_back_to_4x4_all_to_all(capsys):
+    # the parser accepts "complete", the topology builder does not: the driver's fall-back machine
+    arch = driver.build_arch({"topology": "complete", "num_cores_x": 3, "num_cores_y": 3, "ncm_qubits": 4,
+                              "ncp_qubits": 2, "edge_weight_range": (1.0, 2.0)})
+    assert arch.network.number_of_nodes() == 16 and arch.network.number_of_edges() == 120
+    assert arch.qpu_qubit_num == 16
+
+
+def test_topologies_node_and_edge_order():
+    from quantum_simulator_amd.multicore import build_topology
+    g = build_topology("mesh", 2, 3)
+    assert list(g.nodes) == list(range(6))
+    assert list(g.edges()) == [(0, 3), (0, 1), (1, 4), (1, 2), (2, 5), (3, 4), (4, 5)]
+    assert build_topology("tree", 2).number_of_nodes() == 7  # x is the height
+    assert list(build_topology("star", 4).edges()) == [(0, 1), (0, 2), (0, 3)]
+    assert build_topology("torus", 3, 3).number_of_edges() == 18
+    assert list(build_topology("line", 3, 9).edges()) == [(0, 1), (1, 2)]
+    with pytest.raises(ValueError):
+        build_topology("complete", 2, 2)
+
+
+def test_csv_schema(tmp_path):
+    out = tmp_path / "r.csv"
+    driver.write_csv(str(out), ["HQA", "BFS"], [{"file": "a.qasm", "HQA_time_mean": 1.0, "HQA_cost_mean": 386.0}])
+    rows = out.read_text().splitlines()
+    assert rows[0] == "file,HQA_time_mean,HQA_cost_mean,BFS_time_mean,BFS_cost_mean"
+    assert rows[1] == "a.qasm,1.0,386.0,inf,inf"
+
+
+WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, {root!r})
+    import numpy as np
+    import torch.distributed as dist
+    from quantum_simulator_amd import driver
+    dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=2)
+    r = dist.get_rank()
+    sums = np.array([[[10.0 * (r + 1), 1, 0.5, 1]], [[0.0, 0, 0.25 * r, r]]])
+    mins = np.array([[10.0 * (r + 1)], [np.inf]])
+    s, m = driver.reduce_table(sums, mins)
+    assert s[0, 0].tolist() == [30.0, 2.0, 1.0, 2.0], s
+    assert s[1, 0].tolist() == [0.0, 0.0, 0.25, 1.0], s
+    assert m[0, 0] == 10.0 and np.isinf(m[1, 0])
+    dist.destroy_process_group()
+    print("rank", r, "ok")
+""")
+
+
+def test_reduce_two_ranks_gloo(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(WORKER.format(root=ROOT))
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29571")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    for p in procs:
+        out, _ = p.communicate(timeout=180)
+        assert p.returncode == 0, out
+        assert "ok" in out

@@ -86,3 +86,32 @@ def test_not_enough_space_raises():
     arch = multicore(2, 2, ncp_qubits=2, edge_weight_range=(1, 1), network_type="mesh")
     with pytest.raises(ValueError):
         hqa_placer().place_per_timeslice(circ, arch)
+
+
+def test_example_config_end_to_end(tmp_path):
+    """The shipped example config's flow (mesh 2x1, 130 qubits per core, weights in [1, 2], five
+    placers, 3 repeats, one RNG stream) against the costs the reference code produced for the same
+    seed; the circuit is re-serialised from the fixture's gate tables."""
+    from conftest import GOLDEN_INDEX
+    from quantum_simulator_amd import circuit_to_qasm_str, driver
+    gold = GOLDEN_INDEX["example_config"]
+    gc = load_case("gen256_mesh2x1_u")
+    folder = tmp_path / "gen"
+    folder.mkdir()
+    (folder / "256.qasm").write_text(circuit_to_qasm_str(case_circuit(gc)))
+    cfg_path = tmp_path / "cfg.txt"
+    cfg_path.write_text(
+        f"mode = simulate\ntopology = {gold['topology']}\nnum_cores_x = {gold['nx']}\nnum_cores_y = {gold['ny']}\n"
+        f"ncm_qubits = 4\nncp_qubits = {gold['cap']}\nedge_weight_range = {gold['wr'][0]},{gold['wr'][1]}\n"
+        f"circuit_folders = {folder}\nplacers = {', '.join(gold['placers'])}\nrepeats = {gold['repeats']}\n"
+        f"out_csv = {tmp_path / 'out.csv'}\nplot_file = \nseed = {gold['seed']}\n")
+    cfg = driver.parse_config_file(str(cfg_path))
+    res = driver.run_simulation(cfg, verbose=False)[0]
+    for p in gold["placers"]:
+        want = float.fromhex(gold["results"][p]["mean_hex"])
+        got = res[f"{p}_cost_mean"]
+        assert abs(got - want) <= 3e-11 * abs(want), (p, got, want)  # up to ~2.6e5 terms summed left to right
+    w = float.fromhex(gold["edge_weight_hex"])
+    assert round(res["HQA_cost_mean"] / w) == 386 and round(res["TRHQA_cost_mean"] / w) == 386
+    header = (tmp_path / "out.csv").read_text().splitlines()[0]
+    assert header == "file," + ",".join(f"{p}_time_mean,{p}_cost_mean" for p in gold["placers"])

@@ -1,0 +1,197 @@
+"""QUBO path on the GPU.  The reference's solver stack (pyqubo, neal) is not available anywhere this
+code runs and the reference ships no fixture for it, so sample-for-sample parity is unpinned; what is
+checked: the MFMA energies and fields equal the integer CPU restatement of the objective
+(Qubo_placer.py:84-133) exactly, the annealer's bookkeeping equals those energies, brute-force optima
+on tiny models, decode/repair against the oracle, and solution quality."""
+import itertools
+
+import numpy as np
+import pytest
+
+from oracle import placer_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need an MI355X; none is visible")
+    return torch, torch.device("cuda", 0)
+
+
+def _model(Q, T, C, cap, seed, topo="mesh"):
+    from quantum_simulator_amd import layered_gate_arrays
+    from quantum_simulator_amd.engine import hops
+    from quantum_simulator_amd.multicore import build_topology, graph_tables
+    from quantum_simulator_amd.qubo import QuboModel
+    from quantum_simulator_amd.timeslices import CircuitIR
+    rng = np.random.default_rng(seed)
+    q0, q1, _ = layered_gate_arrays(Q, T, 0.5, seed=seed)
+    keep = rng.random(len(q0)) > 0.3
+    ir = CircuitIR.from_gate_tables(Q, q0[keep], q1[keep])
+    side = int(round(C ** 0.5))
+    G = build_topology(topo, side, side) if topo == "mesh" else build_topology(topo, C)
+    nodes, eu, ev, _ = graph_tables(G)
+    H = hops(len(nodes), eu, ev)
+    names = [f"q[{i}]" for i in range(Q)]
+    return QuboModel(ir, len(nodes), cap, H, names), names
+
+
+def _oracle_energy(qm, names, state):
+    act, inter = O.qubo_slices(qm.ir.slices, qm.ir.gate_q, names)
+    assert act == qm.act and inter == qm.inter
+    x = [[[int(state[qm.var_x(t, j, i)]) for i in range(qm.n[t])] for j in range(qm.C)] for t in range(qm.T)]
+    y = [[[int(state[qm.var_y(t, j, p)]) for p in range(qm.cap)] for j in range(qm.C)] for t in range(qm.T)]
+    return O.qubo_energy(act, inter, qm.C, qm.cap, qm.H.tolist(), x, y), x
+
+
+@pytest.mark.parametrize("Q,T,C,cap,seed", [(6, 3, 4, 3, 1), (20, 5, 4, 6, 2), (40, 4, 9, 5, 3), (33, 6, 16, 3, 4)])
+def test_energy_and_fields_exact(gpu, Q, T, C, cap, seed):
+    torch, dev = gpu
+    from quantum_simulator_amd.qubo import DeviceQubo
+    qm, names = _model(Q, T, C, cap, seed)
+    dq = DeviceQubo(qm, dev)
+    rng = np.random.default_rng(seed)
+    R = 128
+    X = np.zeros((R, qm.Npad), np.int8)
+    real = np.zeros(qm.Npad, bool)
+    for t in range(qm.T):
+        real[qm.off[t]:qm.off[t] + qm.Nt[t]] = True
+    X[:, real] = rng.integers(0, 2, size=(R, int(real.sum())))
+    X[0] = 0
+    X[1, real] = 1
+    Xd = torch.from_numpy(X).to(dev)
+    e = dq.energy(Xd).cpu().numpy()
+    for r in list(range(6)) + [R - 1]:
+        want, _ = _oracle_energy(qm, names, X[r])
+        assert e[r] == want, (r, e[r], want)
+    # fields: flipping v changes the energy by (1 - 2 s_v) (a_v + F_v)
+    F = dq.fields(Xd).cpu().numpy()
+    a = qm.linear()
+    for r in (2, 5):
+        base, _ = _oracle_energy(qm, names, X[r])
+        for v in rng.choice(np.flatnonzero(real), size=12, replace=False):
+            s2 = X[r].copy()
+            s2[v] ^= 1
+            want, _ = _oracle_energy(qm, names, s2)
+            assert want - base == (1 - 2 * int(X[r, v])) * (a[v] + F[v, r]), (r, v)
+
+
+def test_energy_bruteforce_optimum_tiny(gpu):
+    """2 qubits, one gate, 2 cores of capacity 2, one slice: all 2^8 states through the MFMA path; the
+    minimum is 0 and is reached exactly by 'both qubits on one core, that core's two slack bits set'."""
+    torch, dev = gpu
+    from quantum_simulator_amd.qubo import DeviceQubo, QuboModel
+    from quantum_simulator_amd.timeslices import CircuitIR
+    ir = CircuitIR(2, [(0, 1)], [False])
+    qm = QuboModel(ir, 2, 2, np.array([[0, 1], [1, 0]]), ["q[0]", "q[1]"])
+    dq = DeviceQubo(qm, dev)
+    X = np.zeros((256, qm.Npad), np.int8)
+    order = [qm.var_x(0, j, i) for j in range(2) for i in range(2)] + [qm.var_y(0, j, p) for j in range(2) for p in range(2)]
+    for s in range(256):
+        for b, v in enumerate(order):
+            X[s, v] = (s >> b) & 1
+    e = dq.energy(torch.from_numpy(X).to(dev)).cpu().numpy()
+    assert e.min() == 0
+    best = np.flatnonzero(e == 0)
+    assert len(best) == 2
+    for s in best:
+        rows = qm.decode(X[s])
+        assert rows[0][0] == rows[0][1]
+    for s in (0, 37, 255):
+        x = [[[int(X[s, qm.var_x(0, j, i)]) for i in range(2)] for j in range(2)]]
+        y = [[[int(X[s, qm.var_y(0, j, p)]) for p in range(2)] for j in range(2)]]
+        assert e[s] == O.qubo_energy([[0, 1]], [[(0, 1)]], 2, 2, [[0, 1], [1, 0]], x, y)
+
+
+@pytest.mark.parametrize("Q,T,C,cap,seed", [(20, 5, 4, 6, 2), (40, 6, 16, 4, 7), (24, 7, 9, 4, 5)])
+def test_anneal_bookkeeping_and_quality(gpu, Q, T, C, cap, seed):
+    torch, dev = gpu
+    from quantum_simulator_amd.qubo import DeviceQubo
+    qm, names = _model(Q, T, C, cap, seed)
+    dq = DeviceQubo(qm, dev)
+    R = 128
+    X0, d0 = dq.anneal(R, 0, seed=9)                 # zero sweeps: the random initial states
+    assert int(d0.abs().max()) == 0
+    e0 = dq.energy(X0)
+    X1, d1 = dq.anneal(R, 300, seed=9)               # same seed: same start
+    e1 = dq.energy(X1)
+    assert torch.equal(e1 - e0, d1), "summed accepted dE must equal the exact energy difference"
+    X2, d2 = dq.anneal(R, 300, seed=9)
+    assert torch.equal(X1, X2) and torch.equal(d1, d2), "same seed, same result"
+    # continuing from given states works and padding stays zero
+    X3, d3 = dq.anneal(R, 50, seed=11, init=X1)
+    assert torch.equal(dq.energy(X3) - e1, d3)
+    pad = np.ones(qm.Npad, bool)
+    for t in range(qm.T):
+        pad[qm.off[t]:qm.off[t] + qm.Nt[t]] = False
+    assert int(X3.cpu().numpy()[:, pad].sum()) == 0
+    # quality: annealing beats both its random start and the block placement (active qubit i of each
+    # slice on core i // cap, slack bits filled), which satisfies every constraint
+    rows0 = []
+    for t in range(qm.T):
+        row = [None] * Q
+        for i, q in enumerate(qm.act[t]):
+            row[q] = i // cap
+        rows0.append(row)
+    block = torch.from_numpy(np.tile(qm.state_from_rows(rows0), (R, 1))).to(dev)
+    e_block = int(dq.energy(block)[0])
+    want, _ = _oracle_energy(qm, names, qm.state_from_rows(rows0))
+    assert e_block == want
+    assert int(e1.min()) < int(e0.min()) and int(e1.min()) <= e_block
+    # decode/repair of the best replica: every active qubit placed, no core over capacity
+    best = int(e1.argmin())
+    state = X1[best].cpu().numpy()
+    _, x = _oracle_energy(qm, names, state)
+    rows = qm.decode(state)
+    act, _ = O.qubo_slices(qm.ir.slices, qm.ir.gate_q, names)
+    assert rows == O.qubo_decode(act, qm.C, qm.cap, x, Q)
+    for t, row in enumerate(rows):
+        placed = [c for c in row if c is not None]
+        assert len(placed) == qm.n[t]
+        if qm.n[t] <= qm.C * qm.cap:
+            assert max(np.bincount(placed, minlength=qm.C)) <= max(qm.cap, -(-qm.n[t] // qm.C))
+
+
+def test_decode_repair_matches_oracle(gpu):
+    torch, dev = gpu
+    qm, names = _model(30, 4, 4, 5, 8)
+    rng = np.random.default_rng(0)
+    act, _ = O.qubo_slices(qm.ir.slices, qm.ir.gate_q, names)
+    for trial in range(20):
+        state = np.zeros(qm.Npad, np.int8)
+        for t in range(qm.T):
+            for i in range(qm.n[t]):
+                for j in range(qm.C):
+                    state[qm.var_x(t, j, i)] = rng.random() < 0.3   # zero, one or several cores per qubit
+        x = [[[int(state[qm.var_x(t, j, i)]) for i in range(qm.n[t])] for j in range(qm.C)] for t in range(qm.T)]
+        assert qm.decode(state) == O.qubo_decode(act, qm.C, qm.cap, x, 30)
+
+
+def test_qubo_placer_end_to_end(gpu):
+    from conftest import case_arch, case_circuit, load_case
+    from quantum_simulator_amd.placers import qubo_placer
+    gc = load_case("shor5_mesh2x2_u")
+    circ, arch = case_circuit(gc), case_arch(gc)
+    placer = qubo_placer(num_sweeps=400)
+    part = placer.place_per_timeslice(circ, arch)
+    assert len(part) == gc.T
+    names = gc.meta["qubits"]
+    qobj = circ.qubits
+    for t, row in enumerate(part):
+        active = {q for g in gc.slices[t] for q in gc.gate_q[g]}
+        assert {qobj.index(q) for q in row} == active
+        load = {}
+        for c in row.values():
+            load[c] = load.get(c, 0) + 1
+        assert max(load.values()) <= gc.cap
+    cost = placer.per_timeslice_cost(circ, part, arch)
+    rows = [[None] * gc.Q for _ in part]
+    for t, row in enumerate(part):
+        for q, c in row.items():
+            rows[t][qobj.index(q)] = c
+    assert cost == O.cost_v4(gc.slices, gc.gate_q, gc.gate_mr, rows, gc.hops.tolist())
+    again = qubo_placer(num_sweeps=400).place_per_timeslice(circ, arch)
+    assert again == part
