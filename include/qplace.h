@@ -70,6 +70,10 @@ typedef struct QpCircuit {
                                        slice order), -1 = empty (HQA_placer.py:227-237) */
     const int32_t* slice_visit_ptr; /* [T+1] CSR over visits */
     const QpVisit* visits;          /* [nV] */
+    const uint32_t* edges_sched;    /* optional [nE]: u | v << 16 of the same gates, grouped by slice like
+                                       `edges` (slice_edge_ptr applies) but in any order inside a slice; the
+                                       cost kernels read this list, so the host may order it to spread the
+                                       LDS banks that consecutive gates' endpoints fall into */
 } QpCircuit;
 
 /* Distance table as the kernels consume it. */

@@ -19,7 +19,7 @@ QP_ABSENT = 0xFF
 class QpCircuit(C.Structure):
     _fields_ = [("Q", C.c_int32), ("T", C.c_int32), ("nE", C.c_int32), ("nV", C.c_int32),
                 ("slice_edge_ptr", C.c_void_p), ("edges", C.c_void_p), ("lookahead", C.c_void_p),
-                ("slice_visit_ptr", C.c_void_p), ("visits", C.c_void_p)]
+                ("slice_visit_ptr", C.c_void_p), ("visits", C.c_void_p), ("edges_sched", C.c_void_p)]
 
 
 class QpDTable(C.Structure):

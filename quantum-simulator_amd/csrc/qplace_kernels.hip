@@ -95,6 +95,7 @@ struct V3Args {
     const uint8_t* A;
     const int32_t* sep;
     const QpEdge* edges;
+    const uint32_t* edges_sched;
     const void* table;
     double* partial;
     int64_t B, nitems;
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3(V3Args p) {
     using E = typename Tab<KIND>::elem;
     using Acc = typename Tab<KIND>::acc;
     const int lane = threadIdx.x & (kWave - 1);
-    const int wave = threadIdx.x / kWave;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // wave-uniform by construction
     uint32_t tab_off = 0;
     const E* tab;
     if constexpr (TABMODE == kTabLds256) {
@@ -218,6 +219,143 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3(V3Args p) {
                 }
                 // the last row of the group becomes "the row before" of the next group
                 if (lane_on && lrow == G - 1) *reinterpret_cast<uint4*>(strip + lq0) = cur;
+            }
+        }
+        const double s = wave_sum(acc);
+        if (lane == 0) p.partial[it] = s;
+    }
+}
+
+// Rows longer than 512 bytes (one row per wave step).  Differences from k_cost_v3: the previous row
+// stays in registers (no LDS round trip), the LDS strip holds only the current row for the edge
+// endpoint gathers, and each row's first kRowEdgeChunks*64 gates are loaded together with the row,
+// kV3Ahead rows ahead, so that vector-memory results are consumed in the order they were requested.
+// Gates come from the scheduled list (u | v << 16), whose order inside a slice the host may choose.
+constexpr int kRowEdgeChunks = 4;
+
+template <int KIND, int TABMODE>
+__global__ __launch_bounds__(kV3Threads) void k_cost_v3_row(V3Args p) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    using E = typename Tab<KIND>::elem;
+    using Acc = typename Tab<KIND>::acc;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // wave-uniform by construction
+    uint32_t tab_off = 0;
+    const E* tab;
+    if constexpr (TABMODE == kTabLds256) {
+        tab_off = stage_table_pitch256<E>(smem, p.table, p.C);
+        tab = reinterpret_cast<const E*>(smem);
+    } else if constexpr (TABMODE == kTabLdsC) {
+        tab_off = stage_table(smem, p.table, p.table_bytes);
+        tab = reinterpret_cast<const E*>(smem);
+    } else {
+        tab = static_cast<const E*>(p.table);
+    }
+    const int ldq = p.ldq;
+    const uint32_t C = (uint32_t)p.C;
+    uint8_t* strip = smem + tab_off + (size_t)wave * ldq;
+    const bool lane_on = lane * 16 < ldq;
+    const int nvalid_row = min(16, max(0, p.Q - lane * 16));
+    uint32_t keep[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const int nb = min(4, max(0, nvalid_row - 4 * w));
+        keep[w] = nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u);
+    }
+    auto pair_at = [&](uint32_t from, uint32_t to) -> Acc {
+        if constexpr (TABMODE == kTabLds256) return tab[(from << 8) | to];
+        else return tab[__umul24(from, C) + to];
+    };
+    auto four = [&](uint32_t pf, uint32_t cf) -> Acc {
+        if constexpr (TABMODE == kTabLds256) {
+            const uint32_t lo = __builtin_amdgcn_perm(pf, cf, 0x05010400u);
+            const uint32_t hi = __builtin_amdgcn_perm(pf, cf, 0x07030602u);
+            return (Acc)tab[lo & 0xFFFFu] + (Acc)tab[lo >> 16] + (Acc)tab[hi & 0xFFFFu] + (Acc)tab[hi >> 16];
+        } else {
+            Acc s = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s += (Acc)tab[__umul24((pf >> (8 * j)) & 0xFFu, C) + ((cf >> (8 * j)) & 0xFFu)];
+            return s;
+        }
+    };
+
+    for (int64_t it = (int64_t)blockIdx.x * kV3Waves + wave; it < p.nitems; it += (int64_t)gridDim.x * kV3Waves) {
+        const int chunk = (int)(it / p.B);
+        const int64_t b = it - (int64_t)chunk * p.B;
+        const int r0 = chunk * p.rows_per_item;
+        const int r1 = min(p.T, r0 + p.rows_per_item);
+        const uint8_t* base = p.A + (size_t)b * p.Tp * ldq;
+        Acc acc = 0;
+
+        // Loads are unconditional (addresses clamped into the item / the gate list) so that the row
+        // loop has no divergent control flow; what they return for a row past the end is never used.
+        const int lane16 = lane_on ? lane * 16 : 0;
+        auto fetch_row = [&](int row) -> uint4 {
+            return *reinterpret_cast<const uint4*>(base + (size_t)min(row, r1 - 1) * ldq + lane16);
+        };
+        // gate `lane` of chunk c of the row (whatever word sits there if the row has fewer gates: the
+        // consumer masks it, so nothing here waits on a loaded value)
+        const int last_gate = p.sep[p.T] - 1;
+        auto fetch_gate = [&](int row, int c) -> uint32_t {
+            const int e = p.sep[min(row, r1 - 1)] + c * kWave + lane;
+            return p.edges_sched[min(e, last_gate)];
+        };
+
+        uint4 prv = make_uint4(0, 0, 0, 0);
+        if (r0 >= 1 && lane_on) prv = *reinterpret_cast<const uint4*>(base + (size_t)(r0 - 1) * ldq + lane * 16);
+        uint4 ring[kV3Ahead];
+        uint32_t gring[kV3Ahead][kRowEdgeChunks];
+#pragma unroll
+        for (int k = 0; k < kV3Ahead; ++k) {
+            ring[k] = fetch_row(r0 + k);
+#pragma unroll
+            for (int c = 0; c < kRowEdgeChunks; ++c) gring[k][c] = fetch_gate(r0 + k, c);
+        }
+
+        for (int g0 = r0; g0 < r1; g0 += kV3Ahead) {
+#pragma unroll
+            for (int k = 0; k < kV3Ahead; ++k) {
+                const int row = g0 + k;
+                if (row >= r1) break;
+                const uint4 cur = ring[k];
+                uint32_t gates[kRowEdgeChunks];
+#pragma unroll
+                for (int c = 0; c < kRowEdgeChunks; ++c) gates[c] = gring[k][c];
+                ring[k] = fetch_row(row + kV3Ahead);
+#pragma unroll
+                for (int c = 0; c < kRowEdgeChunks; ++c) gring[k][c] = fetch_gate(row + kV3Ahead, c);
+
+                if (lane_on) *reinterpret_cast<uint4*>(strip + lane * 16) = cur;
+                // endpoint gathers of the row's gates first, so the movement look-ups overlap them; a
+                // lane without a gate in a chunk uses (0, 0): one qubit twice, distance zero
+                const int ngates = p.sep[row + 1] - p.sep[row];
+                uint32_t au[kRowEdgeChunks], av[kRowEdgeChunks];
+#pragma unroll
+                for (int c = 0; c < kRowEdgeChunks; ++c) {
+                    const uint32_t g = (c * kWave + lane < ngates) ? gates[c] : 0u;
+                    au[c] = strip[g & 0xFFFFu];
+                    av[c] = strip[g >> 16];
+                }
+                const bool mv = lane_on && row >= 2;
+                const uint32_t c0 = mv ? cur.x & keep[0] : 0u, p0 = mv ? prv.x & keep[0] : 0u;
+                const uint32_t c1 = mv ? cur.y & keep[1] : 0u, p1 = mv ? prv.y & keep[1] : 0u;
+                const uint32_t c2 = mv ? cur.z & keep[2] : 0u, p2 = mv ? prv.z & keep[2] : 0u;
+                const uint32_t c3 = mv ? cur.w & keep[3] : 0u, p3 = mv ? prv.w & keep[3] : 0u;
+                const bool moved = ((c0 ^ p0) | (c1 ^ p1) | (c2 ^ p2) | (c3 ^ p3)) != 0;
+                if (__builtin_amdgcn_ballot_w64(moved) != 0)
+                    acc += (four(p0, c0) + four(p1, c1)) + (four(p2, c2) + four(p3, c3));
+                {
+                    Acc s = 0;
+#pragma unroll
+                    for (int c = 0; c < kRowEdgeChunks; ++c) s += pair_at(au[c], av[c]);
+                    acc += s;
+                }
+                const int e1 = __builtin_amdgcn_readfirstlane(p.sep[row + 1]);
+                for (int e = __builtin_amdgcn_readfirstlane(p.sep[row]) + kRowEdgeChunks * kWave + lane; e < e1; e += kWave) {
+                    const uint32_t g = p.edges_sched[e];
+                    acc += pair_at(strip[g & 0xFFFFu], strip[g >> 16]);
+                }
+                prv = cur;
             }
         }
         const double s = wave_sum(acc);
@@ -461,6 +599,7 @@ extern "C" int qp_slice_cost_v3(const QpCircuit* circ, const QpDTable* dt, const
     p.A = A;
     p.sep = circ->slice_edge_ptr;
     p.edges = circ->edges;
+    p.edges_sched = circ->edges_sched;
     p.table = dt->table;
     p.B = B;
     p.T = T;
@@ -488,7 +627,8 @@ extern "C" int qp_slice_cost_v3(const QpCircuit* circ, const QpDTable* dt, const
     const int cus = device_cus();
 
     if (narrow) {
-        const size_t strips = (size_t)kV3Waves * (p.G + 1) * ldq;
+        const bool rowpath = ldq > 512 && circ->edges_sched != nullptr && circ->nE > 0;
+        const size_t strips = rowpath ? (size_t)kV3Waves * ldq : (size_t)kV3Waves * (p.G + 1) * ldq;
         const size_t tab256 = (size_t)dt->C * 256 * esz;
         int mode = kTabGlobal;
         size_t lds = strips;
@@ -501,12 +641,20 @@ extern "C" int qp_slice_cost_v3(const QpCircuit* circ, const QpDTable* dt, const
         }
         const unsigned grid = (unsigned)std::min<int64_t>(cus, (p.nitems + kV3Waves - 1) / kV3Waves);
         void (*kern)(V3Args) = nullptr;
-        if (dt->kind == QP_DT_F64)
+        if (rowpath) {
+            if (dt->kind == QP_DT_F64)
+                kern = mode == kTabLds256 ? k_cost_v3_row<QP_DT_F64, kTabLds256>
+                     : mode == kTabLdsC   ? k_cost_v3_row<QP_DT_F64, kTabLdsC> : k_cost_v3_row<QP_DT_F64, kTabGlobal>;
+            else
+                kern = mode == kTabLds256 ? k_cost_v3_row<QP_DT_U16, kTabLds256>
+                     : mode == kTabLdsC   ? k_cost_v3_row<QP_DT_U16, kTabLdsC> : k_cost_v3_row<QP_DT_U16, kTabGlobal>;
+        } else if (dt->kind == QP_DT_F64) {
             kern = mode == kTabLds256 ? k_cost_v3<QP_DT_F64, kTabLds256>
                  : mode == kTabLdsC   ? k_cost_v3<QP_DT_F64, kTabLdsC> : k_cost_v3<QP_DT_F64, kTabGlobal>;
-        else
+        } else {
             kern = mode == kTabLds256 ? k_cost_v3<QP_DT_U16, kTabLds256>
                  : mode == kTabLdsC   ? k_cost_v3<QP_DT_U16, kTabLdsC> : k_cost_v3<QP_DT_U16, kTabGlobal>;
+        }
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         kern<<<grid, kV3Threads, lds, stream>>>(p);
     } else {

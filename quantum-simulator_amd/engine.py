@@ -105,8 +105,10 @@ class DeviceCircuit:
         self._la = _to_dev(ir.lookahead, self.device)
         self._svp = _to_dev(ir.slice_visit_ptr, self.device)
         self._visits = _to_dev(ir.visit_records, self.device)
+        self._sched = _to_dev(ir.scheduled_edges(), self.device)
         self.c = QpCircuit(ir.Q, ir.T, ir.nE, ir.nV, self._sep.data_ptr(), self._edges.data_ptr(),
-                           self._la.data_ptr(), self._svp.data_ptr(), self._visits.data_ptr())
+                           self._la.data_ptr(), self._svp.data_ptr(), self._visits.data_ptr(),
+                           self._sched.data_ptr())
         self.ldq = (ir.Q + 15) // 16 * 16
 
     @property

@@ -169,6 +169,50 @@ class CircuitIR:
         self.visit_records = rec
         self.slice_visit_ptr = np.asarray(ptr, np.int32)
 
+    def scheduled_edges(self, spread_banks=True) -> np.ndarray:
+        """uint32 (u | v << 16) per counted gate, grouped by slice, ordered inside each slice so that
+        32 consecutive gates (the lanes that share LDS cycles) have their u endpoints, and as far as
+        possible their v endpoints, in different 4-byte LDS banks of the row strip.  The cost is a sum
+        over the slice's gates, so their order is free."""
+        out = (self.edge_u.astype(np.uint32) | (self.edge_v.astype(np.uint32) << 16))
+        if not spread_banks or self.Q <= 64:
+            return out
+        ub = (self.edge_u.astype(np.int64) >> 2) & 31
+        vb = (self.edge_v.astype(np.int64) >> 2) & 31
+        sep = self.slice_edge_ptr
+        for t in range(self.T):
+            a, b = int(sep[t]), int(sep[t + 1])
+            if b - a <= 2:
+                continue
+            pool = list(range(a, b))
+            order = []
+            while pool:
+                used_u, used_v, group, rest = 0, 0, [], []
+                for e in pool:
+                    mu, mv = 1 << int(ub[e]), 1 << int(vb[e])
+                    if len(group) < 32 and not (used_u & mu) and not (used_v & mv):
+                        group.append(e)
+                        used_u |= mu
+                        used_v |= mv
+                    else:
+                        rest.append(e)
+                if len(group) < 32 and rest:  # fill up with gates that clash in one endpoint only, then any
+                    rest2 = []
+                    for e in rest:
+                        mu = 1 << int(ub[e])
+                        if len(group) < 32 and not (used_u & mu):
+                            group.append(e)
+                            used_u |= mu
+                        else:
+                            rest2.append(e)
+                    take = 32 - len(group)
+                    group.extend(rest2[:take])
+                    rest = rest2[take:]
+                order.extend(group)
+                pool = rest
+            out[a:b] = out[order]
+        return out
+
     # -- helpers ----------------------------------------------------------------------------------
     def slice_ops(self, t: int):
         """(edge index, u, v) of the counted gates of slice t, slice order."""
