@@ -237,6 +237,16 @@ def main():
             "roofline": primary["roofline"], "mean_cost": primary["mean_cost"], "min_cost": primary["min_cost"],
             "reduce_ms": primary["reduce_ms"], "qubo": qubo,
         }
+        # HBM bytes per launch as measured with rocprofv3 PMC counters in a separate run of this workload
+        # (profiles/r01_traffic.json; FETCH_SIZE doubled as gfx950 requires for 16-byte-per-lane streams)
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+                tr = json.load(f)
+            wk = tr["workload"]
+            if (wk["Q"], wk["T"], wk["B"], wk["weights"]) == (Q, ir.T, B, args.weights):
+                res["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         if secondary is not None:
             for k in ("_D", "_kind", "_costs"):
                 secondary.pop(k)
