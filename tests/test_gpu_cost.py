@@ -235,3 +235,39 @@ def test_cost_matrix_bits(gpu, name, kind):
         want = np.array(M)
         got = out[b, :len(rops), :len(rav)]
         assert got.tobytes() == want.tobytes(), (name, kind, b)
+
+
+@pytest.mark.parametrize("integer", [True, False])
+def test_cost_v3_full_size_against_c_oracle(gpu, integer):
+    """The benchmark's shape (1024 qubits x 1000 slices, 256 cores) on 48 partitions, dense and sparse
+    movement, against the C restatement (sequential sums): exact for the uint16 table."""
+    torch, engine, eng, dev = gpu
+    import random
+    from oracle import c_oracle
+    from quantum_simulator_amd import layered_gate_arrays
+    from quantum_simulator_amd.multicore import multicore, graph_tables
+    from quantum_simulator_amd.timeslices import CircuitIR
+    Q, T, B = 1024, 1000, 48
+    q0, q1, _ = layered_gate_arrays(Q, T, 0.5, seed=99)
+    ir = CircuitIR.from_gate_tables(Q, q0, q1)
+    random.seed(5)
+    arch = multicore(16, 16, ncp_qubits=8, edge_weight_range=(2.0, 2.0) if integer else (1.0, 3.0), network_type="mesh")
+    nodes, eu, ev, w = graph_tables(arch.network)
+    D = engine.apsp(256, eu, ev, w)
+    dc, dt = engine.DeviceCircuit(ir, dev), engine.DistanceTable(D, dev)
+    rng = np.random.default_rng(1)
+    A = np.empty((B, T, Q), np.uint8)
+    A[:, 0] = np.arange(Q) // 8
+    for t in range(1, T):
+        pm = np.where(np.arange(B) % 3 == 0, 0.02, 0.95)[:, None]
+        move = rng.random((B, Q)) < pm
+        A[:, t] = np.where(move, rng.integers(0, 256, size=(B, Q)), A[:, t - 1])
+    got = eng.cost_v3(dc, dt, torch.from_numpy(A).to(dev)).cpu().numpy()
+    gt = c_oracle.GateTables(ir.slices, ir.gate_q, ir.gate_mr)
+    nterms = ir.nE + T * Q
+    for b in range(B):
+        want = c_oracle.cost_v3(gt, Q, A[b], D)
+        assert _close(got[b], want, integer, nterms), (b, got[b], want)
+    # size-independent property: the cost is additive over a split of the timeline when the second
+    # part starts with a repeated row (no movement is charged for rows 0 and 1 of either part)
+    assert got.tobytes() == eng.cost_v3(dc, dt, torch.from_numpy(A).to(dev)).cpu().numpy().tobytes()

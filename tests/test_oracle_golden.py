@@ -172,3 +172,20 @@ def test_qubo_energy_tiny_bruteforce():
         assert len(cores) == 1 and x[0][cores[0]][1] == 1
         assert sum(y[0][cores[0]]) == 2
         assert O.qubo_decode(act, C, cap, x, 2) == [[cores[0], cores[0]]]
+
+
+@pytest.mark.parametrize("name", ALL_CASES)
+def test_c_oracle_costs_bits(name):
+    """oracle/cost_oracle.c forms the same left-to-right sums: same bits as the reference's floats."""
+    from oracle import c_oracle
+    gc = load_case(name)
+    gt = c_oracle.GateTables(gc.slices, gc.gate_q, gc.gate_mr)
+    for p in ("HQA", "TRHQA", "GTRHQA"):
+        if gc.has(p):
+            assert float(c_oracle.cost_v3(gt, gc.Q, gc.part(p), gc.D)).hex() == gc.meta["placers"][p]["cost_hex"], p
+    for p in ("BFS", "RANDOM"):
+        pm = gc.meta["placers"][p]
+        want = float("inf") if pm["cost_error"] else gc.cost(p)
+        assert c_oracle.cost_v2(gt, gc.Q, gc.part(p), gc.D, 0) == want, p
+        want = float("inf") if pm["v1_error"] else gc.cost_v1(p)
+        assert c_oracle.cost_v2(gt, gc.Q, gc.part(p), gc.D, 1) == want, (p, "v1")
