@@ -100,6 +100,46 @@ def bench_qubo(torch, dev, rank, sweeps, replicas):
                     "only by the energy contraction"}
 
 
+def bench_cost_matrix(torch, dev, dc, ir, D, B, steps):
+    """Secondary metric: op x core cost-matrix entries per second (TRHQA entries: two distance
+    look-ups, six look-ahead slots, the reference's clamp arithmetic).  B instances, each at a different
+    timeslice of the cfg5 circuit with all of its gates as ops and every core available; inputs and
+    the fp64 output are resident in HBM.  The kernel is bound by its 8-byte-per-entry output write."""
+    from quantum_simulator_amd.engine import DistanceTable, Engine, QP_CM_TRHQA
+    import numpy as np
+    C = D.shape[0]
+    dt = DistanceTable(D, dev)
+    eng = Engine(dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    tsel = (np.arange(B) * 7) % (ir.T - 4) + 1
+    n_ops = (ir.slice_edge_ptr[tsel + 1] - ir.slice_edge_ptr[tsel]).astype(np.int32)
+    max_ops = int(n_ops.max())
+    ops = np.zeros((B, max_ops), np.int32)
+    for b in range(B):
+        ops[b, :n_ops[b]] = np.arange(ir.slice_edge_ptr[tsel[b]], ir.slice_edge_ptr[tsel[b] + 1])
+    a = torch.randint(0, C, (B, dc.ldq), device=dev, generator=g, dtype=torch.int16).to(torch.uint8)
+    avail = torch.arange(C, device=dev, dtype=torch.int16).to(torch.uint8).expand(B, C).contiguous()
+    args = [torch.from_numpy(tsel.astype(np.int32)).to(dev), a, torch.from_numpy(ops).to(dev),
+            torch.from_numpy(n_ops).to(dev), avail, torch.full((B,), C, dtype=torch.int32, device=dev)]
+    out = torch.empty((B, max_ops, C), dtype=torch.float64, device=dev)
+    eng.cost_matrix(QP_CM_TRHQA, dc, dt, *args, out=out)
+    torch.cuda.synchronize(dev)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record(torch.cuda.current_stream(dev))
+    for _ in range(steps):
+        eng.cost_matrix(QP_CM_TRHQA, dc, dt, *args, out=out)
+    ev1.record(torch.cuda.current_stream(dev))
+    torch.cuda.synchronize(dev)
+    ms = ev0.elapsed_time(ev1) / steps
+    entries = int(n_ops.sum()) * C
+    gbs = entries * 8 / (ms * 1e-3) / 1e9
+    return {"kind": "TRHQA", "instances": B, "entries_per_launch": entries, "kernel_ms": ms,
+            "entries_per_s": entries / (ms * 1e-3),
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                         "note": "8 bytes written per entry; inputs are re-read from cache"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -131,7 +171,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -211,6 +251,13 @@ def main():
     if not args.single:
         secondary = run_variant("uniform" if args.weights == "integer" else "integer")
 
+    cm = None
+    if not args.no_qubo:
+        cm = bench_cost_matrix(torch, dev, dc, ir, primary["_D"], min(B, 2048), 5)
+        if world > 1:
+            fl = torch.tensor([cm["entries_per_s"]], dtype=torch.float64, device=dev)
+            dist.all_reduce(fl, op=dist.ReduceOp.SUM)
+            cm["entries_per_s"] = float(fl.item())
     qubo = None
     if not args.no_qubo:
         del A
@@ -235,7 +282,7 @@ def main():
                        "seeds": {"circuit": circ_seed, "weights": weight_seed, "partitions": "777+rank"},
                        "table": primary["table"]},
             "roofline": primary["roofline"], "mean_cost": primary["mean_cost"], "min_cost": primary["min_cost"],
-            "reduce_ms": primary["reduce_ms"], "qubo": qubo,
+            "reduce_ms": primary["reduce_ms"], "cost_matrix": cm, "qubo": qubo,
         }
         # HBM bytes per launch as measured with rocprofv3 PMC counters in a separate run of this workload
         # (profiles/r01_traffic.json; FETCH_SIZE doubled as gfx950 requires for 16-byte-per-lane streams)
@@ -286,7 +333,7 @@ def main():
                                    "python_port_evals_per_s": n_py * ir.T / t_py if n_py else None,
                                    "host_cpus": os.cpu_count(), "affinity": len(os.sched_getaffinity(0))}
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -496,50 +496,63 @@ struct CmArgs {
 
 __device__ inline double pymax(double a, double b) { return b > a ? b : a; }  // Python's max(a, b)
 
+// One workgroup = one instance x kCmOps consecutive ops; thread j owns available-core column j.
+// Everything that depends on the op only (its qubits' cores, the cores of the look-ahead partners) is
+// the same for all threads, so the compiler keeps it in scalar registers; per thread there are two
+// distance loads, six compares and one coalesced 8-byte store per entry.
+constexpr int kCmOps = 16;
+
 __global__ __launch_bounds__(256) void k_cost_matrix(CmArgs p) {
     const int64_t b = blockIdx.y;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = idx / p.C, j = idx - i * p.C;
-    if (i >= p.n_ops[b] || j >= p.n_avail[b]) return;
-    const int eid = p.ops[(size_t)b * p.max_ops + i];
-    const QpEdge ed = p.edges[eid];
+    const int n_ops = p.n_ops[b], n_av = p.n_avail[b];
+    const int i0 = blockIdx.x * kCmOps;
+    if (i0 >= n_ops) return;
+    const int i1 = min(n_ops, i0 + kCmOps);
     const uint8_t* a = p.a + (size_t)b * p.ldq;
-    const uint32_t c = p.avail[(size_t)b * p.C + j];
-    const uint32_t a1 = a[ed.u], a2 = a[ed.v];
-    double r;
-    if (p.kind == QP_CM_GTRHQA) {
-        // a core whose label is 0 is "falsy" in the reference: leaving core 0 costs nothing
-        double cost = 0.0;
-        if (a1 != 0 && a1 != c) cost += p.D[a1 * p.C + c];
-        if (a2 != 0 && a2 != c) cost += p.D[a2 * p.C + c];
-        r = cost;
-    } else {
-        double att = 0.0;
-        const int16_t* la = p.lookahead + (size_t)eid * 6;
+    const int C = p.C;
+    for (int j = threadIdx.x; j < n_av; j += blockDim.x) {
+        const uint32_t c = p.avail[(size_t)b * C + j];
+        for (int i = i0; i < i1; ++i) {
+            const int eid = p.ops[(size_t)b * p.max_ops + i];
+            const QpEdge ed = p.edges[eid];
+            const uint32_t a1 = a[ed.u], a2 = a[ed.v];
+            const double d1 = p.D[a1 * C + c], d2 = p.D[a2 * C + c];
+            double r;
+            if (p.kind == QP_CM_GTRHQA) {
+                // a core whose label is 0 is "falsy" in the reference: leaving core 0 costs nothing
+                double cost = 0.0;
+                if (a1 != 0 && a1 != c) cost += d1;
+                if (a2 != 0 && a2 != c) cost += d2;
+                r = cost;
+            } else {
+                double att = 0.0;
+                const int16_t* la = p.lookahead + (size_t)eid * 6;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const int o = la[k];
-            if (o >= 0) {
-                const double w = k < 2 ? 0.5 : (k < 4 ? 0.25 : 0.125);
-                att += (a[o] == c) ? w * 0.9 : w * 0.3;
+                for (int k = 0; k < 6; ++k) {
+                    const int o = la[k];
+                    if (o >= 0) {
+                        const double w = k < 2 ? 0.5 : (k < 4 ? 0.25 : 0.125);
+                        att += (a[o] == c) ? w * 0.9 : w * 0.3;
+                    }
+                }
+                if (p.kind == QP_CM_HQA) {
+                    const double m = (double)((a1 != c) + (a2 != c));
+                    r = pymax(0.1, pymax(0.1, m - att));
+                } else {
+                    double mv = 0.0;
+                    if (a1 != c) mv += d1;
+                    if (a2 != c) mv += d2;
+                    const double T_ = pymax(0.1, mv - att);
+                    double here = 0.0;
+                    if (a1 != 0 && a1 != c) here += d1;
+                    if (a2 != 0 && a2 != c) here += d2;
+                    const double attraction = here - T_;
+                    r = pymax(0.1, here - attraction);
+                }
             }
-        }
-        if (p.kind == QP_CM_HQA) {
-            const double m = (double)((a1 != c) + (a2 != c));
-            r = pymax(0.1, pymax(0.1, m - att));
-        } else {
-            double mv = 0.0;
-            if (a1 != c) mv += p.D[a1 * p.C + c];
-            if (a2 != c) mv += p.D[a2 * p.C + c];
-            const double T_ = pymax(0.1, mv - att);
-            double here = 0.0;
-            if (a1 != 0 && a1 != c) here += p.D[a1 * p.C + c];
-            if (a2 != 0 && a2 != c) here += p.D[a2 * p.C + c];
-            const double attraction = here - T_;
-            r = pymax(0.1, here - attraction);
+            p.out[((size_t)b * p.max_ops + i) * C + j] = r;
         }
     }
-    p.out[((size_t)b * p.max_ops + i) * p.C + j] = r;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -753,7 +766,7 @@ extern "C" int qp_cost_matrix(int32_t kind, const QpCircuit* circ, const QpDTabl
     p.ldq = ldq;
     p.max_ops = max_ops;
     p.kind = kind;
-    const dim3 grid((unsigned)(((int64_t)max_ops * dt->C + 255) / 256), (unsigned)B);
+    const dim3 grid((unsigned)((max_ops + kCmOps - 1) / kCmOps), (unsigned)B);
     k_cost_matrix<<<grid, 256, 0, static_cast<hipStream_t>(stream_)>>>(p);
     HIP_TRY(hipGetLastError());
     return QP_OK;
