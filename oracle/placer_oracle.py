@@ -448,13 +448,13 @@ def _make_space(a, occ, cap, C, D):
                     break
 
 
-def place_hqa_family(slices, gate_q, gate_mr, Q, C, cap, D, kind, record=None):
+def place_hqa_family(slices, gate_q, gate_mr, Q, C, cap, D, kind, record=None, init=None):
     """``kind`` 'hqa': HQA_placer.py:20-176; 'trhqa': TRHQA_placer.py:22-228.  Returns T rows.
     ``record`` (a list) receives (t, ops, avail, matrix, live assignment) for every LSAP call."""
     if Q > C * cap:
         raise ValueError("Not enough space")
     T = len(slices)
-    part = [[int(i / cap) for i in range(Q)]]
+    part = [list(init) if init is not None else [int(i / cap) for i in range(Q)]]
     for t in range(1, T):
         prev = part[t - 1]
         a = list(prev)
@@ -563,13 +563,13 @@ def gtrhqa_rounds(M):
     return out
 
 
-def place_gtrhqa(slices, gate_q, gate_mr, Q, C, cap, D, record=None):
+def place_gtrhqa(slices, gate_q, gate_mr, Q, C, cap, D, record=None, init=None):
     """GTRHQA_placer.py:20-267.  Returns T+1 rows: the loop starts at slice 0, slice t reads row
     t-1 (row 0 for t = 0) and appends row t+1."""
     if Q > C * cap:
         raise ValueError("Not enough space")
     T = len(slices)
-    init = [int(i / cap) for i in range(Q)]
+    init = list(init) if init is not None else [int(i / cap) for i in range(Q)]
     part = [init]
     for t in range(T):
         prev = part[t - 1] if t > 0 else init

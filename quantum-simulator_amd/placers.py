@@ -256,6 +256,94 @@ class _HqaFamily(BasePlacer):
             rows.append(a)
         return rows
 
+    # -- many instances in lock-step ----------------------------------------------------------------
+    def place_batch(self, circuit, multicore_arch, initial=None, B=None, threads=8):
+        """B independent placements of one circuit on one architecture, advanced slice by slice
+        together: one qp_cost_matrix launch and one qp_lsap_f64_batch call per while-iteration serve
+        every instance that is still working on the slice.  ``initial`` is uint8 [B, Q] (row 0 of each
+        instance; default: B copies of the block assignment, i.e. B identical repeats as main.py:88-92
+        runs them).  Returns uint8 [B, T, Q]; instance b equals what ``place_per_timeslice`` gives when
+        started from ``initial[b]``."""
+        import torch
+        ctx = self._context(circuit, multicore_arch)
+        cap = multicore_arch.qpu_qubit_num
+        ir, C, D = ctx.ir, ctx.arch.C, ctx.arch.D
+        Q, T = ir.Q, ir.T
+        self._check_capacity(Q, C, cap)
+        if initial is None:
+            initial = np.tile(self._initial(Q, cap), (B or 1, 1))
+        initial = np.ascontiguousarray(initial, np.uint8)
+        B = initial.shape[0]
+        out = np.empty((B, self._rows_out(T), Q), np.uint8)
+        out[:, 0] = initial
+        dev = ctx.device
+        sep = ir.slice_edge_ptr
+        base_off = (np.arange(B, dtype=np.int64) * C)[:, None]
+        for t in range(1, T):
+            a = out[:, t - 1].copy()
+            e0, e1 = int(sep[t]), int(sep[t + 1])
+            if e1 == e0:
+                out[:, t] = a
+                continue
+            eu, ev = ir.edge_u[e0:e1].astype(np.int64), ir.edge_v[e0:e1].astype(np.int64)
+            rem = a[:, eu] != a[:, ev]                      # [B, E] ops still to place
+            budget = rem.sum(1) + 1
+            spent = np.zeros(B, np.int64)
+            occ = np.bincount((a.astype(np.int64) + base_off).ravel(), minlength=B * C).reshape(B, C)
+            while True:
+                live = rem.any(1) & (spent < budget)
+                if not live.any():
+                    break
+                spent[live] += 1
+                room = occ <= cap - 2
+                has = room.any(1)
+                for b in np.flatnonzero(live & ~has):
+                    self._make_space(a[b], occ[b], cap, C, D)
+                go = np.flatnonzero(live & has)
+                if go.size == 0:
+                    continue
+                n_ops = rem[go].sum(1).astype(np.int32)
+                n_av = room[go].sum(1).astype(np.int32)
+                max_ops = int(n_ops.max())
+                ops = np.zeros((go.size, max_ops), np.int32)
+                avail = np.zeros((go.size, C), np.uint8)
+                op_lists, av_lists = [], []
+                for k, b in enumerate(go):
+                    idx = np.flatnonzero(rem[b])
+                    av = np.flatnonzero(room[b])
+                    ops[k, :idx.size] = e0 + idx
+                    avail[k, :av.size] = av
+                    op_lists.append(idx)
+                    av_lists.append(av)
+                ab = np.zeros((go.size, ctx.dc.ldq), np.uint8)
+                ab[:, :Q] = a[go]
+                M = ctx.eng.cost_matrix(
+                    self._kind, ctx.dc, ctx.arch.table, torch.full((go.size,), t, dtype=torch.int32, device=dev),
+                    torch.from_numpy(ab).to(dev), torch.from_numpy(ops).to(dev), torch.from_numpy(n_ops).to(dev),
+                    torch.from_numpy(avail).to(dev), torch.from_numpy(n_av).to(dev)).cpu().numpy()
+                rr, cc, status = E.lsap_batch(M, n_ops, n_av, threads)
+                for k, b in enumerate(go):
+                    if status[k] != 0:          # the reference swallows the solver's exception: slice ends
+                        spent[b] = budget[b]
+                        continue
+                    m = min(int(n_ops[k]), int(n_av[k]))
+                    for i, j in zip(rr[k, :m].tolist(), cc[k, :m].tolist()):
+                        if M[k, i, j] != np.inf:
+                            e = op_lists[k][i]
+                            u, v, core = int(eu[e]), int(ev[e]), int(av_lists[k][j])
+                            occ[b, a[b, u]] -= 1
+                            occ[b, a[b, v]] -= 1
+                            a[b, u] = core
+                            a[b, v] = core
+                            occ[b, core] += 2
+                            rem[b, e] = False
+            out[:, t] = a
+        return out
+
+    @staticmethod
+    def _rows_out(T):
+        return T
+
     @staticmethod
     def _make_space(a, occ, cap, C, D):
         """HQA_placer.py:180-204: from every core above cap-2, move up to two of its qubits (lowest
@@ -321,6 +409,63 @@ class gtrhqa_placer(_HqaFamily):
                         a[v] = avail[j]
             rows.append(a)
         return rows
+
+
+def _gtrhqa_place_batch(self, circuit, multicore_arch, initial=None, B=None, threads=8):
+    """GTRHQA in lock-step: one cost-matrix launch per slice for all instances, then the greedy
+    rounds per instance on the host.  Returns uint8 [B, T+1, Q] (the reference's T+1 rows)."""
+    import torch
+    ctx = self._context(circuit, multicore_arch)
+    cap = multicore_arch.qpu_qubit_num
+    ir, C = ctx.ir, ctx.arch.C
+    Q, T = ir.Q, ir.T
+    self._check_capacity(Q, C, cap)
+    if initial is None:
+        initial = np.tile(self._initial(Q, cap), (B or 1, 1))
+    initial = np.ascontiguousarray(initial, np.uint8)
+    B = initial.shape[0]
+    out = np.empty((B, T + 1, Q), np.uint8)
+    out[:, 0] = initial
+    dev = ctx.device
+    sep = ir.slice_edge_ptr
+    base_off = (np.arange(B, dtype=np.int64) * C)[:, None]
+    for t in range(T):
+        a = (out[:, t - 1] if t > 0 else initial).copy()
+        e0, e1 = int(sep[t]), int(sep[t + 1])
+        if e1 > e0:
+            eu, ev = ir.edge_u[e0:e1].astype(np.int64), ir.edge_v[e0:e1].astype(np.int64)
+            rem = a[:, eu] != a[:, ev]
+            occ = np.bincount((a.astype(np.int64) + base_off).ravel(), minlength=B * C).reshape(B, C)
+            room = occ <= cap - 2
+            go = np.flatnonzero(rem.any(1) & room.any(1))
+            if go.size:
+                n_ops = rem[go].sum(1).astype(np.int32)
+                n_av = room[go].sum(1).astype(np.int32)
+                ops = np.zeros((go.size, int(n_ops.max())), np.int32)
+                avail = np.zeros((go.size, C), np.uint8)
+                op_lists, av_lists = [], []
+                for k, b in enumerate(go):
+                    idx, av = np.flatnonzero(rem[b]), np.flatnonzero(room[b])
+                    ops[k, :idx.size] = e0 + idx
+                    avail[k, :av.size] = av
+                    op_lists.append(idx)
+                    av_lists.append(av)
+                ab = np.zeros((go.size, ctx.dc.ldq), np.uint8)
+                ab[:, :Q] = a[go]
+                M = ctx.eng.cost_matrix(
+                    QP_CM_GTRHQA, ctx.dc, ctx.arch.table, torch.full((go.size,), t, dtype=torch.int32, device=dev),
+                    torch.from_numpy(ab).to(dev), torch.from_numpy(ops).to(dev), torch.from_numpy(n_ops).to(dev),
+                    torch.from_numpy(avail).to(dev), torch.from_numpy(n_av).to(dev)).cpu().numpy()
+                for k, b in enumerate(go):
+                    for i, j in greedy_rounds(M[k, :n_ops[k], :n_av[k]]):
+                        e = op_lists[k][i]
+                        a[b, eu[e]] = av_lists[k][j]
+                        a[b, ev[e]] = av_lists[k][j]
+        out[:, t + 1] = a
+    return out
+
+
+gtrhqa_placer.place_batch = _gtrhqa_place_batch
 
 
 def greedy_rounds(M: np.ndarray):
