@@ -73,6 +73,9 @@ __device__ inline uint32_t stage_table_pitch256(uint8_t* smem, const void* table
 constexpr int kTabLds256 = 0;  // LDS, row pitch 256 entries: index = from << 8 | to
 constexpr int kTabLdsC = 1;    // LDS, row pitch C
 constexpr int kTabGlobal = 2;  // device memory (L2-resident), row pitch C
+constexpr int kTabLdsBand = 3; // LDS holds rows [band_lo, band_lo + band_rows) at pitch 256 plus one zero entry;
+                               // pairs whose source core is outside the band read the zero entry, and the
+                               // launcher runs one pass per band (for fp64 tables too big for LDS)
 
 // ------------------------------------------------------------------------------------------------
 // Cost V3: dense partitions, HQA-family definition.
@@ -101,6 +104,7 @@ struct V3Args {
     int64_t B, nitems;
     int32_t T, Tp, ldq, Q, C, rows_per_item, G, lpr;
     uint32_t table_bytes;
+    int32_t band_lo, band_rows;
 };
 
 template <int KIND, int TABMODE>
@@ -248,11 +252,27 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_row(V3Args p) {
     } else if constexpr (TABMODE == kTabLdsC) {
         tab_off = stage_table(smem, p.table, p.table_bytes);
         tab = reinterpret_cast<const E*>(smem);
+    } else if constexpr (TABMODE == kTabLdsBand) {
+        const E* src = static_cast<const E*>(p.table) + (size_t)p.band_lo * p.C;
+        E* dst = reinterpret_cast<E*>(smem);
+        for (int k = threadIdx.x; k <= p.band_rows * 256; k += blockDim.x) {
+            const int r = k >> 8, c = k & 255;
+            dst[k] = (r < p.band_rows && c < p.C) ? src[r * p.C + c] : E(0);
+        }
+        __syncthreads();
+        tab_off = (uint32_t)(((size_t)(p.band_rows * 256 + 1) * sizeof(E) + 15) & ~(size_t)15);
+        tab = reinterpret_cast<const E*>(smem);
     } else {
         tab = static_cast<const E*>(p.table);
     }
     const int ldq = p.ldq;
     const uint32_t C = (uint32_t)p.C;
+    const uint32_t band_base = (uint32_t)p.band_lo << 8, band_span = (uint32_t)p.band_rows << 8;
+    // (from << 8 | to) -> slot of the band table; everything outside the band -> the zero entry
+    auto band_slot = [&](uint32_t code) -> uint32_t {
+        const uint32_t x = code - band_base;
+        return x < band_span ? x : band_span;
+    };
     uint8_t* strip = smem + tab_off + (size_t)wave * ldq;
     const bool lane_on = lane * 16 < ldq;
     const int nvalid_row = min(16, max(0, p.Q - lane * 16));
@@ -264,6 +284,7 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_row(V3Args p) {
     }
     auto pair_at = [&](uint32_t from, uint32_t to) -> Acc {
         if constexpr (TABMODE == kTabLds256) return tab[(from << 8) | to];
+        else if constexpr (TABMODE == kTabLdsBand) return tab[band_slot((from << 8) | to)];
         else return tab[__umul24(from, C) + to];
     };
     auto four = [&](uint32_t pf, uint32_t cf) -> Acc {
@@ -271,6 +292,11 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_row(V3Args p) {
             const uint32_t lo = __builtin_amdgcn_perm(pf, cf, 0x05010400u);
             const uint32_t hi = __builtin_amdgcn_perm(pf, cf, 0x07030602u);
             return (Acc)tab[lo & 0xFFFFu] + (Acc)tab[lo >> 16] + (Acc)tab[hi & 0xFFFFu] + (Acc)tab[hi >> 16];
+        } else if constexpr (TABMODE == kTabLdsBand) {
+            const uint32_t lo = __builtin_amdgcn_perm(pf, cf, 0x05010400u);
+            const uint32_t hi = __builtin_amdgcn_perm(pf, cf, 0x07030602u);
+            return (Acc)tab[band_slot(lo & 0xFFFFu)] + (Acc)tab[band_slot(lo >> 16)] +
+                   (Acc)tab[band_slot(hi & 0xFFFFu)] + (Acc)tab[band_slot(hi >> 16)];
         } else {
             Acc s = 0;
 #pragma unroll
@@ -591,7 +617,7 @@ extern "C" size_t qp_slice_cost_workspace(int32_t T, int64_t B) {
     if (T <= 0 || B <= 0) return 16;
     // one double per (chunk, partition); chunks are never shorter than 16 rows unless T is
     const int64_t max_chunks = (T + 15) / 16 + 1;
-    return (size_t)(max_chunks * B) * sizeof(double);
+    return (size_t)(max_chunks * B) * sizeof(double) * 4;  // up to four table-band passes
 }
 
 extern "C" int qp_slice_cost_v3(const QpCircuit* circ, const QpDTable* dt, const uint8_t* A, int64_t B, int32_t Tp,
@@ -654,6 +680,27 @@ extern "C" int qp_slice_cost_v3(const QpCircuit* circ, const QpDTable* dt, const
         }
         const unsigned grid = (unsigned)std::min<int64_t>(cus, (p.nitems + kV3Waves - 1) / kV3Waves);
         void (*kern)(V3Args) = nullptr;
+        if (rowpath && mode == kTabGlobal && dt->kind == QP_DT_F64) {
+            // fp64 table too big for LDS: one pass per band of source cores, each with its band in LDS
+            const int band_rows = (int)std::min<size_t>(dt->C, ((size_t)kLdsBytes - strips - 16) / (256 * esz));
+            const int passes = (dt->C + band_rows - 1) / band_rows;
+            if (workspace_bytes < (size_t)passes * p.nitems * sizeof(double))
+                return qp::fail(QP_ENOSPC, "qp_slice_cost_v3: workspace needs %zu bytes", (size_t)passes * p.nitems * sizeof(double));
+            kern = k_cost_v3_row<QP_DT_F64, kTabLdsBand>;
+            const size_t band_lds = strips + (((size_t)band_rows * 256 + 1) * esz + 15) / 16 * 16;
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)band_lds));
+            for (int k = 0; k < passes; ++k) {
+                V3Args q = p;
+                q.band_lo = k * band_rows;
+                q.band_rows = std::min(band_rows, dt->C - q.band_lo);
+                q.partial = p.partial + (size_t)k * p.nitems;
+                kern<<<grid, kV3Threads, band_lds, stream>>>(q);
+            }
+            HIP_TRY(hipGetLastError());
+            k_sum_chunks<<<(unsigned)((B + 255) / 256), 256, 0, stream>>>(p.partial, B, nchunks * passes, out);
+            HIP_TRY(hipGetLastError());
+            return QP_OK;
+        }
         if (rowpath) {
             if (dt->kind == QP_DT_F64)
                 kern = mode == kTabLds256 ? k_cost_v3_row<QP_DT_F64, kTabLds256>
