@@ -182,7 +182,7 @@ int qp_cost_matrix(int32_t kind, const QpCircuit* circ, const QpDTable* dt, int6
 typedef struct QpQuboSeg {
     const int8_t* mat; /* dev */
     int32_t ld;        /* row pitch in bytes */
-    int32_t K;         /* columns, multiple of 64 */
+    int32_t K;         /* columns, multiple of 128 */
     int64_t xoff;      /* first variable (padded axis) the columns refer to */
 } QpQuboSeg;
 

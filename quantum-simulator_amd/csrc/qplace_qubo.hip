@@ -24,14 +24,14 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 //
 // Workgroup = 4 waves (2 x 2), tile = 128 variables x 128 replicas, each wave 64 x 64 as 2 x 2 MFMA
 // tiles.  Both operands are contiguous along the contraction axis (S row-major, states stored
-// replica-major), so a lane's A or B fragment is 16 consecutive bytes.  Tiles go through LDS with an
-// 80-byte row pitch: 16 consecutive rows then start in 16 different 16-byte slots of the 256-byte
+// replica-major), so a lane's A or B fragment is 16 consecutive bytes.  Tiles go through LDS with a
+// 144-byte row pitch: 16 consecutive rows then start in 16 different 16-byte slots of the 256-byte
 // bank row, which is what ds_read_b128 needs to run conflict-free.
 // ------------------------------------------------------------------------------------------------
 
 constexpr int kTile = 128;
-constexpr int kBK = 64;
-constexpr int kPitch = 80;
+constexpr int kBK = 128;
+constexpr int kPitch = 144;  // 128 + 16: consecutive rows start 9 sixteen-byte slots apart (odd => conflict-free)
 
 struct GemmArgs {
     const QpQuboSeg* segs;
@@ -64,23 +64,44 @@ __global__ __launch_bounds__(256) void k_qubo_gemm(GemmArgs p) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[a][b][k] = 0;
 
-    // staging: thread -> (row = tid / 4 [+64], 16-byte piece = tid % 4) of a 128 x 64 byte tile
-    const int srow = tid >> 2, spiece = tid & 3;
+    // staging: thread -> (row = tid / 8 + 32 i, 16-byte piece = tid % 8) of a 128 x 128 byte tile; the
+    // next tile's global loads are issued before the current tile's MFMAs so they overlap
+    const int srow = tid >> 3, spiece = tid & 7;
+    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+#define QP_LOAD_TILE(Ab, Bb, ld, k0)                                                                          \
+    do {                                                                                                      \
+        const int8_t* pa_ = (Ab) + (size_t)srow * (ld) + (k0) + spiece * 16;                                  \
+        const int8_t* pb_ = (Bb) + (size_t)srow * p.Npad + (k0) + spiece * 16;                                \
+        ra0 = *reinterpret_cast<const uint4*>(pa_);                                                           \
+        ra1 = *reinterpret_cast<const uint4*>(pa_ + (size_t)32 * (ld));                                       \
+        ra2 = *reinterpret_cast<const uint4*>(pa_ + (size_t)64 * (ld));                                       \
+        ra3 = *reinterpret_cast<const uint4*>(pa_ + (size_t)96 * (ld));                                       \
+        rb0 = *reinterpret_cast<const uint4*>(pb_);                                                           \
+        rb1 = *reinterpret_cast<const uint4*>(pb_ + (size_t)32 * p.Npad);                                     \
+        rb2 = *reinterpret_cast<const uint4*>(pb_ + (size_t)64 * p.Npad);                                     \
+        rb3 = *reinterpret_cast<const uint4*>(pb_ + (size_t)96 * p.Npad);                                     \
+    } while (0)
     for (int sg = p.seg_ptr[t]; sg < p.seg_ptr[t + 1]; ++sg) {
         const QpQuboSeg seg = p.segs[sg];
         const int8_t* Ab = seg.mat + (size_t)vrow * seg.ld;
         const int8_t* Bb = p.Xt + (size_t)r0 * p.Npad + seg.xoff;
+        QP_LOAD_TILE(Ab, Bb, seg.ld, 0);
         for (int k0 = 0; k0 < seg.K; k0 += kBK) {
-            const uint4 a0 = *reinterpret_cast<const uint4*>(Ab + (size_t)srow * seg.ld + k0 + spiece * 16);
-            const uint4 a1 = *reinterpret_cast<const uint4*>(Ab + (size_t)(srow + 64) * seg.ld + k0 + spiece * 16);
-            const uint4 b0 = *reinterpret_cast<const uint4*>(Bb + (size_t)srow * p.Npad + k0 + spiece * 16);
-            const uint4 b1 = *reinterpret_cast<const uint4*>(Bb + (size_t)(srow + 64) * p.Npad + k0 + spiece * 16);
             __syncthreads();
-            *reinterpret_cast<uint4*>(sA + srow * kPitch + spiece * 16) = a0;
-            *reinterpret_cast<uint4*>(sA + (srow + 64) * kPitch + spiece * 16) = a1;
-            *reinterpret_cast<uint4*>(sB + srow * kPitch + spiece * 16) = b0;
-            *reinterpret_cast<uint4*>(sB + (srow + 64) * kPitch + spiece * 16) = b1;
+            {
+                int8_t* wa = sA + srow * kPitch + spiece * 16;
+                int8_t* wb = sB + srow * kPitch + spiece * 16;
+                *reinterpret_cast<uint4*>(wa) = ra0;
+                *reinterpret_cast<uint4*>(wa + 32 * kPitch) = ra1;
+                *reinterpret_cast<uint4*>(wa + 64 * kPitch) = ra2;
+                *reinterpret_cast<uint4*>(wa + 96 * kPitch) = ra3;
+                *reinterpret_cast<uint4*>(wb) = rb0;
+                *reinterpret_cast<uint4*>(wb + 32 * kPitch) = rb1;
+                *reinterpret_cast<uint4*>(wb + 64 * kPitch) = rb2;
+                *reinterpret_cast<uint4*>(wb + 96 * kPitch) = rb3;
+            }
             __syncthreads();
+            if (k0 + kBK < seg.K) QP_LOAD_TILE(Ab, Bb, seg.ld, k0 + kBK);
 #pragma unroll
             for (int kk = 0; kk < kBK / 32; ++kk) {
                 v4i fa[2], fb[2];
@@ -100,6 +121,7 @@ __global__ __launch_bounds__(256) void k_qubo_gemm(GemmArgs p) {
         }
     }
 
+#undef QP_LOAD_TILE
     // accumulator element k of lane l: row (k & 3) + 8 * (k >> 2) + 4 * (l >> 5), column l & 31
     const int h = lane >> 5;
     if constexpr (!ENERGY) {
