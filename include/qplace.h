@@ -205,11 +205,11 @@ typedef struct QpQuboStruct {
     int64_t Npad;
     const int32_t* n;       /* [T] active qubits per slice */
     const int64_t* off;     /* [T+1] */
-    const uint8_t* deg;     /* [T*nmax] interaction-graph degree */
-    const int32_t* nbr_ptr; /* [T*nmax+1] CSR over interaction partners (local indices of the slice) */
+    const uint64_t* info;   /* [T*nmax] per (slice, active qubit): bits 0-7 interaction-graph degree,
+                               16-31 first interaction partner (local index), 32-47 index of the same qubit
+                               in slice t+1 (int16, -1: inactive there), 48-63 same for slice t-1 */
+    const int32_t* nbr_ptr; /* [T*nmax+1] CSR over interaction partners (used when the degree is > 1) */
     const int16_t* nbr;
-    const int16_t* nxt;     /* [T*nmax] index of the same qubit in slice t+1, -1 if inactive there */
-    const int16_t* prv;     /* [T*nmax] same for slice t-1 */
     const uint8_t* hops;    /* [C*C] hop counts */
 } QpQuboStruct;
 

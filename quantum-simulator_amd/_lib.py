@@ -38,8 +38,8 @@ class QpQuboDense(C.Structure):
 
 class QpQuboStruct(C.Structure):
     _fields_ = [("T", C.c_int32), ("C", C.c_int32), ("cap", C.c_int32), ("nmax", C.c_int32), ("Npad", C.c_int64),
-                ("n", C.c_void_p), ("off", C.c_void_p), ("deg", C.c_void_p), ("nbr_ptr", C.c_void_p),
-                ("nbr", C.c_void_p), ("nxt", C.c_void_p), ("prv", C.c_void_p), ("hops", C.c_void_p)]
+                ("n", C.c_void_p), ("off", C.c_void_p), ("info", C.c_void_p), ("nbr_ptr", C.c_void_p),
+                ("nbr", C.c_void_p), ("hops", C.c_void_p)]
 
 
 QP_QUBO_INIT_GIVEN = 1

@@ -211,13 +211,17 @@ __global__ __launch_bounds__(256) void k_qubo_anneal(SaArgs p) {
     const QpQuboStruct& m = p.m;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = blockIdx.x * (blockDim.x >> 6) + wave;
-    if (r >= p.R) return;
     const int T = m.T, C = m.C, cap = m.cap, nmax = m.nmax;
     // per-wave LDS: mask[T][nmax] u32, load[T][C] i32, slack[T][C] u32
     const size_t per_wave = ((size_t)T * nmax + 2 * (size_t)T * C) * 4;
-    uint32_t* mask = reinterpret_cast<uint32_t*>(smem + wave * per_wave);
+    const size_t hop_bytes = ((size_t)C * C + 15) & ~(size_t)15;
+    uint8_t* hop = smem;  // hop counts, shared by the block's replicas
+    for (int k = threadIdx.x; k < C * C; k += blockDim.x) hop[k] = m.hops[k];
+    __syncthreads();
+    uint32_t* mask = reinterpret_cast<uint32_t*>(smem + hop_bytes + wave * per_wave);
     int32_t* load = reinterpret_cast<int32_t*>(mask + (size_t)T * nmax);
     uint32_t* slack = reinterpret_cast<uint32_t*>(load + (size_t)T * C);
+    if (r >= p.R) return;  // after the block-wide barrier above
     int8_t* X = p.Xt + (size_t)r * m.Npad;
     uint32_t rng = mix32(p.seed * 0x100000001B3ull + ((uint64_t)r << 8) + lane);
     const uint32_t capmask = cap >= 32 ? 0xFFFFFFFFu : ((1u << cap) - 1u);
@@ -290,17 +294,24 @@ __global__ __launch_bounds__(256) void k_qubo_anneal(SaArgs p) {
                             const int bit = (w >> lj) & 1u;
                             const int d = 1 - 2 * bit;
                             const int Ai = __popc(w);
-                            int lap = m.deg[tb + i];
-                            for (int e = m.nbr_ptr[tb + i]; e < m.nbr_ptr[tb + i + 1]; ++e)
-                                lap -= 2 * (int)((mk[m.nbr[e]] >> lj) & 1u);
+                            // packed per-qubit record: degree | first partner | same qubit in t+1 | in t-1
+                            const uint64_t inf = m.info[tb + i];
+                            const int dg = (int)(inf & 0xFFu);
+                            int lap = dg;
+                            if (dg == 1) {
+                                lap -= 2 * (int)((mk[(int)((inf >> 16) & 0xFFFFu)] >> lj) & 1u);
+                            } else if (dg > 1) {
+                                for (int e = m.nbr_ptr[tb + i]; e < m.nbr_ptr[tb + i + 1]; ++e)
+                                    lap -= 2 * (int)((mk[m.nbr[e]] >> lj) & 1u);
+                            }
                             int mv = 0;
-                            const int ix = m.nxt[tb + i], ip = m.prv[tb + i];
+                            const int ix = (int)(int16_t)((inf >> 32) & 0xFFFFu), ip = (int)(int16_t)((inf >> 48) & 0xFFFFu);
                             if (ix >= 0) {
                                 uint32_t o = mask[(size_t)(t + 1) * nmax + ix];
                                 while (o) {
                                     const int l = __ffs(o) - 1;
                                     o &= o - 1;
-                                    mv += m.hops[lj * C + l];
+                                    mv += hop[lj * C + l];
                                 }
                             }
                             if (ip >= 0) {
@@ -308,7 +319,7 @@ __global__ __launch_bounds__(256) void k_qubo_anneal(SaArgs p) {
                                 while (o) {
                                     const int l = __ffs(o) - 1;
                                     o &= o - 1;
-                                    mv += m.hops[l * C + lj];
+                                    mv += hop[l * C + lj];
                                 }
                             }
                             const int dE = 4 * d * (2 * (Ai - 1) + d) + 4 * d * (2 * L + d) + 10 * d * (lap + mv);
@@ -408,7 +419,7 @@ extern "C" int qp_qubo_anneal(const QpQuboStruct* m, int32_t R, int32_t sweeps, 
     if (m->T <= 0 || m->C <= 0 || m->C > 32 || m->cap <= 0 || m->cap > 32 || m->nmax <= 0)
         return qp::fail(QP_EINVAL, "qp_qubo_anneal: needs 1..32 cores and capacity 1..32");
     if (R <= 0 || sweeps < 0 || !(beta_hot > 0) || !(beta_cold > 0)) return qp::fail(QP_EINVAL, "qp_qubo_anneal: bad R/sweeps/beta");
-    if (!m->n || !m->off || !m->deg || !m->nbr_ptr || !m->nxt || !m->prv || !m->hops)
+    if (!m->n || !m->off || !m->info || !m->nbr_ptr || !m->hops)
         return qp::fail(QP_EINVAL, "qp_qubo_anneal: model tables missing");
     const size_t per_wave = ((size_t)m->T * m->nmax + 2 * (size_t)m->T * m->C) * 4;
     int waves = 4;
@@ -424,7 +435,7 @@ extern "C" int qp_qubo_anneal(const QpQuboStruct* m, int32_t R, int32_t sweeps, 
     a.beta_hot = (float)beta_hot;
     a.beta_ratio_log = (float)std::log(beta_cold / beta_hot);
     a.seed = seed;
-    const size_t lds = per_wave * waves;
+    const size_t lds = per_wave * waves + (((size_t)m->C * m->C + 15) & ~(size_t)15);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_qubo_anneal), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     k_qubo_anneal<<<(R + waves - 1) / waves, waves * 64, lds, static_cast<hipStream_t>(stream_)>>>(a);
     HIP_TRY(hipGetLastError());

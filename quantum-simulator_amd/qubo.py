@@ -264,10 +264,19 @@ class DeviceQubo:
                 ptr[t * nmax + i + 1] = len(nbr)
         if m.H.max() > 255:
             raise ValueError("hop counts above 255 are not supported")
+        first = np.zeros((m.T, nmax), np.uint64)
+        for t in range(m.T):
+            for i in range(int(m.n[t])):
+                a, b = ptr[t * nmax + i], ptr[t * nmax + i + 1]
+                if b > a:
+                    first[t, i] = nbr[a]
+        info = (deg.astype(np.uint64) | (first << np.uint64(16))
+                | ((nxt.astype(np.int64) & 0xFFFF).astype(np.uint64) << np.uint64(32))
+                | ((prv.astype(np.int64) & 0xFFFF).astype(np.uint64) << np.uint64(48)))
         self.struct = _lib.QpQuboStruct(m.T, m.C, m.cap, nmax, m.Npad, up(m.n.astype(np.int32)).data_ptr(),
-                                        off.data_ptr(), up(deg).data_ptr(), up(ptr).data_ptr(),
-                                        up(np.asarray(nbr if nbr else [0], np.int16)).data_ptr(), up(nxt).data_ptr(),
-                                        up(prv).data_ptr(), up(m.H.astype(np.uint8)).data_ptr())
+                                        off.data_ptr(), up(info).data_ptr(), up(ptr).data_ptr(),
+                                        up(np.asarray(nbr if nbr else [0], np.int16)).data_ptr(),
+                                        up(m.H.astype(np.uint8)).data_ptr())
 
     def _stream(self):
         return self._C.c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
