@@ -115,6 +115,20 @@ int qp_lsap_f64_batch(int32_t n, const int32_t* nr, const int32_t* nc, const dou
                       int32_t ld, int32_t* row_out, int32_t* col_out, int32_t out_stride, int32_t* status,
                       int32_t threads);
 
+/* ASAP timeslices of a circuit of one- and two-qubit gates (gq1[g] = -1 for one qubit), host.
+ * Same slice membership AND same order inside every slice as BasePlacer.break_into_timeslices
+ * (Placer.py:14-61), whose order depends on how CPython iterates its successor sets; that iteration
+ * order is reproduced.  order_out[n_gates]: gate indices slice after slice; slice_ptr_out[<= n_gates+1];
+ * *T_out: number of slices. */
+int qp_timeslices(int32_t n_gates, const int32_t* gq0, const int32_t* gq1, int32_t Q, int32_t* order_out,
+                  int32_t* slice_ptr_out, int32_t* T_out);
+
+/* Orders the counted gates of every slice for QpCircuit.edges_sched (u | v << 16): runs of 32 gates get
+ * endpoints in distinct 4-byte LDS banks where possible.  No reference counterpart (the cost is a sum
+ * over a slice's gates; their order is free). */
+int qp_schedule_gates(int32_t T, const int32_t* slice_edge_ptr, const uint16_t* eu, const uint16_t* ev,
+                      uint32_t* sched_out);
+
 /* Chooses the device representation of a host distance matrix and writes it into a host staging
  * buffer the caller then copies to the device (C*C*8 bytes is always enough).  The diagonal is
  * forced to 0 (the reference never adds a term for equal cores).  Returns the kind in *kind_out. */

@@ -59,6 +59,9 @@ EXPORTS = {
     "qp_lsap_f64": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "qp_lsap_f64_batch": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                                     C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]),
+    "qp_timeslices": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                C.POINTER(C.c_int32)]),
+    "qp_schedule_gates": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "qp_dtable_pack": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.POINTER(C.c_int32),
                                  C.POINTER(C.c_size_t)]),
     "qp_slice_cost_workspace": (C.c_size_t, [C.c_int32, C.c_int64]),

@@ -326,3 +326,130 @@ extern "C" int qp_dtable_pack(const double* D, int32_t C, void* staging, size_t 
     }
     return QP_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Timeslicing (ASAP layering with the reference's within-slice order) and gate scheduling
+// ------------------------------------------------------------------------------------------------
+
+namespace {
+
+// Iteration order of a CPython set that received the small non-negative ints a then b (a != b):
+// 8-slot table, slot = value & 7, on collision i = (5 i + 1 + (perturb >>= 5)) & 7 with perturb = value;
+// iteration walks the slots upwards.  Returns true when b comes out before a.
+inline bool second_first(int64_t a, int64_t b) {
+    const unsigned sa = (unsigned)(a & 7);
+    unsigned i = (unsigned)(b & 7);
+    uint64_t perturb = (uint64_t)b;
+    while (i == sa) {
+        perturb >>= 5;
+        i = (unsigned)((i * 5u + 1u + perturb) & 7u);
+    }
+    return i < sa;
+}
+
+}  // namespace
+
+extern "C" int qp_timeslices(int32_t n_gates, const int32_t* gq0, const int32_t* gq1, int32_t Q, int32_t* order_out,
+                             int32_t* slice_ptr_out, int32_t* T_out) {
+    if (n_gates < 0 || Q <= 0 || !T_out || (n_gates > 0 && (!gq0 || !gq1 || !order_out || !slice_ptr_out)))
+        return qp::fail(QP_EINVAL, "qp_timeslices: bad argument");
+    std::vector<int32_t> last(Q, -1);
+    std::vector<int32_t> pred((size_t)n_gates * 2, -1), succ((size_t)n_gates * 2, -1);
+    for (int32_t g = 0; g < n_gates; ++g) {
+        const int32_t qs[2] = {gq0[g], gq1[g]};
+        if (qs[0] < 0 || qs[0] >= Q || qs[1] >= Q || qs[1] == qs[0]) return qp::fail(QP_EINVAL, "qp_timeslices: gate %d has bad qubits", g);
+        for (int k = 0; k < 2; ++k) {
+            const int32_t q = qs[k];
+            if (q < 0) continue;
+            const int32_t pg = last[q];
+            if (pg >= 0) {
+                int32_t* pp = &pred[(size_t)g * 2];
+                if (pp[0] != pg && pp[1] != pg) pp[pp[0] < 0 ? 0 : 1] = pg;  // predecessors[g].add(pg)
+                int32_t* sp = &succ[(size_t)pg * 2];
+                if (sp[0] != g && sp[1] != g) sp[sp[0] < 0 ? 0 : 1] = g;      // successors[pg].add(g)
+            }
+            last[q] = g;
+        }
+    }
+    std::vector<int32_t> ready, next, busy(Q, -1);
+    std::vector<char> done(n_gates, 0);
+    for (int32_t g = 0; g < n_gates; ++g)
+        if (pred[(size_t)g * 2] < 0) ready.push_back(g);
+    int32_t T = 0, n_out = 0;
+    slice_ptr_out[0] = 0;
+    while (!ready.empty()) {
+        const int32_t begin = n_out;
+        for (int32_t g : ready) {
+            const int32_t a = gq0[g], b = gq1[g];
+            if (busy[a] == T || (b >= 0 && busy[b] == T)) continue;  // a gate queued twice: second copy
+            busy[a] = T;
+            if (b >= 0) busy[b] = T;
+            done[g] = 1;
+            order_out[n_out++] = g;
+        }
+        next.clear();
+        for (int32_t k = begin; k < n_out; ++k) {
+            const int32_t g = order_out[k];
+            int32_t s0 = succ[(size_t)g * 2], s1 = succ[(size_t)g * 2 + 1];
+            if (s1 >= 0 && second_first(s0, s1)) std::swap(s0, s1);
+            for (int32_t sgate : {s0, s1}) {
+                if (sgate < 0 || done[sgate]) continue;
+                const int32_t p0 = pred[(size_t)sgate * 2], p1 = pred[(size_t)sgate * 2 + 1];
+                if (done[p0] && (p1 < 0 || done[p1])) next.push_back(sgate);
+            }
+        }
+        ++T;
+        slice_ptr_out[T] = n_out;
+        ready.swap(next);
+    }
+    *T_out = T;
+    return QP_OK;
+}
+
+extern "C" int qp_schedule_gates(int32_t T, const int32_t* slice_edge_ptr, const uint16_t* eu, const uint16_t* ev,
+                                 uint32_t* sched_out) {
+    if (T < 0 || !slice_edge_ptr || (slice_edge_ptr[T] > 0 && (!eu || !ev || !sched_out)))
+        return qp::fail(QP_EINVAL, "qp_schedule_gates: bad argument");
+    std::vector<int32_t> pool, rest, group;
+    for (int32_t t = 0; t < T; ++t) {
+        const int32_t a = slice_edge_ptr[t], b = slice_edge_ptr[t + 1];
+        pool.clear();
+        for (int32_t e = a; e < b; ++e) pool.push_back(e);
+        int32_t w = a;
+        while (!pool.empty()) {
+            uint32_t used_u = 0, used_v = 0;
+            group.clear();
+            rest.clear();
+            for (int32_t e : pool) {  // gates whose two endpoints fall into LDS banks nobody in the group uses
+                const uint32_t mu = 1u << ((eu[e] >> 2) & 31), mv = 1u << ((ev[e] >> 2) & 31);
+                if (group.size() < 32 && !(used_u & mu) && !(used_v & mv)) {
+                    group.push_back(e);
+                    used_u |= mu;
+                    used_v |= mv;
+                } else {
+                    rest.push_back(e);
+                }
+            }
+            if (group.size() < 32 && !rest.empty()) {  // then gates that clash in one endpoint only, then any
+                pool.clear();
+                for (int32_t e : rest) {
+                    const uint32_t mu = 1u << ((eu[e] >> 2) & 31);
+                    if (group.size() < 32 && !(used_u & mu)) {
+                        group.push_back(e);
+                        used_u |= mu;
+                    } else {
+                        pool.push_back(e);
+                    }
+                }
+                rest.clear();
+                for (int32_t e : pool) {
+                    if (group.size() < 32) group.push_back(e);
+                    else rest.push_back(e);
+                }
+            }
+            for (int32_t e : group) sched_out[w++] = (uint32_t)eu[e] | ((uint32_t)ev[e] << 16);
+            pool.swap(rest);
+        }
+    }
+    return QP_OK;
+}

@@ -56,20 +56,123 @@ def slice_gate_indices(gate_q: Sequence[Tuple[int, ...]]) -> List[List[int]]:
     return slices
 
 
+def native_slices(Q: int, q0: np.ndarray, q1: np.ndarray):
+    """Same result as ``slice_gate_indices`` for circuits of one- and two-qubit gates, computed by
+    qp_timeslices (host C++).  Returns (order, slice_ptr): gate indices slice after slice + CSR."""
+    import ctypes as C
+    from . import _lib
+    q0 = np.ascontiguousarray(q0, np.int32)
+    q1 = np.ascontiguousarray(q1, np.int32)
+    n = len(q0)
+    order = np.empty(max(n, 1), np.int32)
+    ptr = np.empty(n + 2, np.int32)
+    T = C.c_int32(0)
+    _lib.check(_lib.lib().qp_timeslices(n, _lib.ptr(q0), _lib.ptr(q1), Q, _lib.ptr(order), _lib.ptr(ptr), C.byref(T)))
+    return order[:n], ptr[:T.value + 1].copy()
+
+
 class CircuitIR:
     """Integer view of one circuit.  Build with ``CircuitIR.from_circuit`` or ``from_gate_tables``."""
 
-    def __init__(self, Q: int, gate_q, gate_mr, slices=None, qubits=None, commands=None):
+    def __init__(self, Q: int, gate_q, gate_mr, slices=None, qubits=None, commands=None, tables=None):
         self.Q = int(Q)
         self.gate_q = [tuple(int(x) for x in g) for g in gate_q]
         self.gate_mr = [bool(x) for x in gate_mr]
+        n = len(self.gate_q)
+        small = all(len(g) <= 2 for g in self.gate_q)
+        if tables is not None:
+            q0, q1 = tables
+        elif small:
+            q0 = np.fromiter((g[0] for g in self.gate_q), np.int32, n)
+            q1 = np.fromiter((g[1] if len(g) == 2 else -1 for g in self.gate_q), np.int32, n)
+        if slices is None and small:
+            order, ptr = native_slices(self.Q, q0, q1)
+            slices = [order[ptr[t]:ptr[t + 1]].tolist() for t in range(len(ptr) - 1)]
         self.slices = slices if slices is not None else slice_gate_indices(self.gate_q)
         self.T = len(self.slices)
         self.qubits = qubits          # circuit.qubits order (objects), or None
         self.commands = commands      # command objects in file order, or None
-        self._build_edges()
-        self._build_lookahead()
-        self._build_visits()
+        if small:
+            self._build_tables_vectorised(q0, q1)
+        else:
+            self._build_edges()
+            self._build_lookahead()
+            self._build_visits()
+
+    def _build_tables_vectorised(self, q0, q1):
+        """Edges, look-ahead and visits for circuits of one- and two-qubit gates, with numpy only."""
+        T, Q = self.T, self.Q
+        order = np.fromiter((g for layer in self.slices for g in layer), np.int64, sum(len(x) for x in self.slices))
+        sizes = np.fromiter((len(x) for x in self.slices), np.int64, T)
+        gptr = np.concatenate([[0], np.cumsum(sizes)])
+        gt = np.repeat(np.arange(T, dtype=np.int64), sizes)          # slice of each ordered gate
+        gpos = np.arange(len(order), dtype=np.int64) - gptr[gt]       # position inside its slice
+        a, b = q0[order].astype(np.int64), q1[order].astype(np.int64)
+        mr = np.asarray(self.gate_mr, bool)[order] if len(order) else np.zeros(0, bool)
+        two = b >= 0
+        counted = two & ~mr
+        # edges
+        ce = np.flatnonzero(counted)
+        self.nE = len(ce)
+        self.edge_u = a[ce].astype(np.uint16)
+        self.edge_v = b[ce].astype(np.uint16)
+        self.edge_t = gt[ce].astype(np.int32)
+        self.slice_edge_ptr = np.concatenate([[0], np.cumsum(np.bincount(gt[ce], minlength=T))]).astype(np.int32)
+        self.edge_of_gate = dict(zip(order[ce].tolist(), range(self.nE)))
+        rec = np.zeros(self.nE, dtype=np.dtype([("u", "<u2"), ("v", "<u2"), ("t", "<i4")]))
+        rec["u"], rec["v"], rec["t"] = self.edge_u, self.edge_v, self.edge_t
+        self.edge_records = rec
+        # look-ahead: per (slice, qubit) the two-qubit command holding it
+        la = np.full((self.nE, 6), -1, np.int16)
+        if self.nE and T > 1:
+            pos = np.full((T, Q), -1, np.int32)
+            first = np.zeros((T, Q), np.int32)
+            second = np.zeros((T, Q), np.int32)
+            tw = np.flatnonzero(two)
+            for x in (a[tw], b[tw]):
+                pos[gt[tw], x] = gpos[tw]
+                first[gt[tw], x] = a[tw]
+                second[gt[tw], x] = b[tw]
+            u = self.edge_u.astype(np.int64)
+            v = self.edge_v.astype(np.int64)
+            for dt in (1, 2, 3):
+                tt = self.edge_t.astype(np.int64) + dt
+                ok = tt < T
+                tc = np.where(ok, tt, 0)
+                cand = []
+                for x in (u, v):
+                    p = np.where(ok, pos[tc, x], -1)
+                    f1, f2 = first[tc, x], second[tc, x]
+                    cand.append((p, np.where((f1 == u) | (f1 == v), f2, f1)))
+                (pu, ou), (pv, ov) = cand
+                pv = np.where(pv == pu, -1, pv)
+                swap = (pu < 0) | ((pv >= 0) & (pv < pu))
+                p1, o1 = np.where(swap, pv, pu), np.where(swap, ov, ou)
+                p2, o2 = np.where(swap, pu, pv), np.where(swap, ou, ov)
+                la[:, 2 * (dt - 1)] = np.where(p1 >= 0, o1, -1)
+                la[:, 2 * (dt - 1) + 1] = np.where(p2 >= 0, o2, -1)
+        self.lookahead = la
+        # visits: (gate, qubit) in slice order; second qubit of a two-qubit gate right after the first
+        nv = len(order) + int(two.sum())
+        vidx = np.arange(len(order), dtype=np.int64) + np.concatenate([[0], np.cumsum(two)[:-1]]) if len(order) else np.zeros(0, np.int64)
+        vq = np.empty(nv, np.int64)
+        vt = np.empty(nv, np.int64)
+        vp = np.full(nv, 0xFFFF, np.int64)
+        vq[vidx], vt[vidx] = a, gt
+        vp[vidx] = np.where(counted, b, 0xFFFF)
+        v2 = vidx[two] + 1
+        vq[v2], vt[v2] = b[two], gt[two]
+        # previous slice in which the same qubit was visited: neighbour in a stable sort by qubit
+        srt = np.argsort(vq, kind="stable")
+        prev = np.full(nv, -1, np.int64)
+        same = vq[srt][1:] == vq[srt][:-1]
+        prev[srt[1:][same]] = vt[srt[:-1][same]]
+        self.nV = nv
+        rec = np.zeros(nv, dtype=np.dtype([("q", "<u2"), ("partner", "<u2"), ("t", "<i4"), ("prev_t", "<i4"), ("pad", "<i4")]))
+        rec["q"], rec["partner"], rec["t"], rec["prev_t"] = vq, vp, vt, prev
+        self.visit_records = rec
+        nvis = np.bincount(gt, weights=1 + two.astype(np.int64), minlength=T).astype(np.int64) if len(order) else np.zeros(T, np.int64)
+        self.slice_visit_ptr = np.concatenate([[0], np.cumsum(nvis)]).astype(np.int32)
 
     # -- construction ---------------------------------------------------------------------------
     @classmethod
@@ -84,8 +187,10 @@ class CircuitIR:
 
     @classmethod
     def from_gate_tables(cls, Q, q0, q1, mr=None, slices=None) -> "CircuitIR":
-        gate_q = [(int(a),) if b < 0 else (int(a), int(b)) for a, b in zip(q0, q1)]
-        return cls(Q, gate_q, mr if mr is not None else [False] * len(gate_q), slices=slices)
+        q0 = np.ascontiguousarray(q0, np.int32)
+        q1 = np.ascontiguousarray(q1, np.int32)
+        gate_q = [(a,) if b < 0 else (a, b) for a, b in zip(q0.tolist(), q1.tolist())]
+        return cls(Q, gate_q, mr if mr is not None else [False] * len(gate_q), slices=slices, tables=(q0, q1))
 
     def _build_edges(self):
         eu, ev, et, ptr = [], [], [], [0]
@@ -175,43 +280,15 @@ class CircuitIR:
         possible their v endpoints, in different 4-byte LDS banks of the row strip.  The cost is a sum
         over the slice's gates, so their order is free."""
         out = (self.edge_u.astype(np.uint32) | (self.edge_v.astype(np.uint32) << 16))
-        if not spread_banks or self.Q <= 64:
+        if not spread_banks or self.Q <= 64 or self.nE == 0:
             return out
-        ub = (self.edge_u.astype(np.int64) >> 2) & 31
-        vb = (self.edge_v.astype(np.int64) >> 2) & 31
-        sep = self.slice_edge_ptr
-        for t in range(self.T):
-            a, b = int(sep[t]), int(sep[t + 1])
-            if b - a <= 2:
-                continue
-            pool = list(range(a, b))
-            order = []
-            while pool:
-                used_u, used_v, group, rest = 0, 0, [], []
-                for e in pool:
-                    mu, mv = 1 << int(ub[e]), 1 << int(vb[e])
-                    if len(group) < 32 and not (used_u & mu) and not (used_v & mv):
-                        group.append(e)
-                        used_u |= mu
-                        used_v |= mv
-                    else:
-                        rest.append(e)
-                if len(group) < 32 and rest:  # fill up with gates that clash in one endpoint only, then any
-                    rest2 = []
-                    for e in rest:
-                        mu = 1 << int(ub[e])
-                        if len(group) < 32 and not (used_u & mu):
-                            group.append(e)
-                            used_u |= mu
-                        else:
-                            rest2.append(e)
-                    take = 32 - len(group)
-                    group.extend(rest2[:take])
-                    rest = rest2[take:]
-                order.extend(group)
-                pool = rest
-            out[a:b] = out[order]
-        return out
+        from . import _lib
+        eu = np.ascontiguousarray(self.edge_u, np.uint16)
+        ev = np.ascontiguousarray(self.edge_v, np.uint16)
+        sep = np.ascontiguousarray(self.slice_edge_ptr, np.int32)
+        sched = np.empty(self.nE, np.uint32)
+        _lib.check(_lib.lib().qp_schedule_gates(self.T, _lib.ptr(sep), _lib.ptr(eu), _lib.ptr(ev), _lib.ptr(sched)))
+        return sched
 
     # -- helpers ----------------------------------------------------------------------------------
     def slice_ops(self, t: int):

@@ -163,3 +163,50 @@ def test_qasm_reader_matches_fixture_tables():
         ir = CircuitIR.from_circuit(circuit_from_qasm(os.path.join(ref, gc.meta["qasm"]), maxwidth=1024))
         assert ir.gate_q == gc.gate_q and ir.gate_mr == gc.gate_mr and ir.slices == gc.slices
         assert [str(q) for q in ir.qubits] == gc.meta["qubits"]
+
+
+@pytest.mark.parametrize("name", ALL_CASES)
+def test_native_timeslices_match_reference(name):
+    """qp_timeslices reproduces the reference's slices, order inside each slice included."""
+    from quantum_simulator_amd.timeslices import native_slices
+    gc = load_case(name)
+    q0 = np.array([g[0] for g in gc.gate_q], np.int32)
+    q1 = np.array([g[1] if len(g) == 2 else -1 for g in gc.gate_q], np.int32)
+    order, ptr = native_slices(gc.Q, q0, q1)
+    got = [order[ptr[t]:ptr[t + 1]].tolist() for t in range(len(ptr) - 1)]
+    assert got == gc.slices
+
+
+def test_native_timeslices_random_vs_python_sets():
+    """Random circuits, including gate indices that collide in CPython's 8-slot set table."""
+    from quantum_simulator_amd.timeslices import native_slices
+    rng = np.random.default_rng(2)
+    for trial in range(60):
+        Q = int(rng.integers(2, 40))
+        n = int(rng.integers(1, 600))
+        q0 = rng.integers(0, Q, size=n).astype(np.int32)
+        q1 = rng.integers(0, Q, size=n).astype(np.int32)
+        one = (rng.random(n) < 0.4) | (q1 == q0)
+        q1[one] = -1
+        gate_q = [(int(a),) if b < 0 else (int(a), int(b)) for a, b in zip(q0, q1)]
+        order, ptr = native_slices(Q, q0, q1)
+        got = [order[ptr[t]:ptr[t + 1]].tolist() for t in range(len(ptr) - 1)]
+        assert got == slice_gate_indices(gate_q), trial
+    with pytest.raises(_lib.QplaceError):
+        native_slices(4, np.array([0], np.int32), np.array([0], np.int32))  # both operands the same qubit
+
+
+def test_scheduled_gates_are_a_per_slice_permutation():
+    from quantum_simulator_amd import layered_gate_arrays
+    q0, q1, _ = layered_gate_arrays(300, 12, 0.5, seed=8)
+    ir = CircuitIR.from_gate_tables(300, q0, q1)
+    plain, sched = ir.scheduled_edges(False), ir.scheduled_edges(True)
+    assert plain.tolist() == (ir.edge_u.astype(np.uint32) | (ir.edge_v.astype(np.uint32) << 16)).tolist()
+    worse = 0
+    for t in range(ir.T):
+        a, b = ir.slice_edge_ptr[t], ir.slice_edge_ptr[t + 1]
+        assert sorted(plain[a:b].tolist()) == sorted(sched[a:b].tolist())
+        for arr, sign in ((plain, 1), (sched, -1)):
+            banks = ((arr[a:a + 32] & 0xFFFF) >> 2) & 31
+            worse += sign * (32 - len(set(banks.tolist())))
+    assert worse > 0, "the schedule should spread the first 32 gates' endpoints over more banks"
