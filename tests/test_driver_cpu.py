@@ -117,3 +117,73 @@ def test_reduce_two_ranks_gloo(tmp_path):
         out, _ = p.communicate(timeout=180)
         assert p.returncode == 0, out
         assert "ok" in out
+
+
+SHARD_WORKER = textwrap.dedent("""
+    import json, os, sys
+    sys.path.insert(0, {root!r})
+    import torch.distributed as dist
+    from quantum_simulator_amd import driver, placers
+
+    class Fake:
+        '''Deterministic stand-in: the cost depends on the circuit size and on how often this
+        instance was asked, so a wrong shard or a double count shows up in the mean.'''
+        def __init__(self, device=None):
+            self.calls = 0
+        def place_per_timeslice(self, circuit, arch):
+            return [dict()]
+        def per_timeslice_cost(self, circuit, part, arch):
+            self.calls += 1
+            if circuit.n_gates % 7 == 3 and self.calls == 1:
+                raise KeyError("simulated failure")      # becomes inf for that repeat only
+            return float(circuit.n_gates * 10 + circuit.n_qubits)
+
+    placers.PLACERS.clear()
+    placers.PLACERS.update({{"HQA": Fake, "TRHQA": Fake}})
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=world)
+    cfg = driver.parse_config_file({cfg!r})
+    cfg["out_csv"] = {out!r} + os.environ.get("RANK", "0")
+    res = driver.run_simulation(cfg, device="cpu", verbose=False)
+    print("RESULT " + json.dumps([[r[k] for k in sorted(r) if k.endswith("cost_mean") or k.endswith("cost_min")] for r in res]))
+    if world > 1:
+        dist.destroy_process_group()
+""")
+
+
+def test_sharded_run_equals_single_rank(tmp_path):
+    from quantum_simulator_amd import circuit_to_qasm_str, layered_circuit
+    folder = tmp_path / "circ"
+    folder.mkdir()
+    for k, (q, t) in enumerate([(6, 4), (9, 3), (5, 7)]):
+        (folder / f"c{k}.qasm").write_text(circuit_to_qasm_str(layered_circuit(q, t, 0.5, seed=k)))
+    cfg = tmp_path / "cfg.txt"
+    cfg.write_text(EXAMPLE.replace("circuits/gen", str(folder)).replace("RANDOM, BFS, TRHQA, HQA, GTRHQA", "HQA, TRHQA")
+                   .replace("repeats = 3", "repeats = 5").replace("results_plot.png", "") + "seed = 3\n")
+    script = tmp_path / "w.py"
+    script.write_text(SHARD_WORKER.format(root=ROOT, cfg=str(cfg), out=str(tmp_path / "out.csv")))
+
+    def run(world):
+        procs = []
+        for r in range(world):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT="29572")
+            procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                          stderr=subprocess.STDOUT, text=True))
+        outs = []
+        for p in procs:
+            out, _ = p.communicate(timeout=240)
+            assert p.returncode == 0, out
+            outs.append([l for l in out.splitlines() if l.startswith("RESULT ")][0])
+        return outs
+
+    single = run(1)[0]
+    double = run(2)
+    assert double[0] == double[1], "every rank must end with the full table"
+    import json
+    a, b = json.loads(single[7:]), json.loads(double[0][7:])
+    assert len(a) == 3
+    for ra, rb in zip(a, b):
+        for x, y in zip(ra, rb):
+            assert x == y or (math.isinf(x) and math.isinf(y))
+    assert (tmp_path / "out.csv0").exists() and not (tmp_path / "out.csv1").exists()  # rank 0 writes the CSV
