@@ -147,7 +147,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--weights", choices=["uniform", "integer"], default="integer",
                     help="edge weights of the headline number: integer (2,2) -> exact uint16 table in LDS; "
-                         "uniform(1,3) -> fp64 table; the other one is run too and reported under other_weights")
+                         "uniform(1,3) -> fp64 table; the other one is run too and reported under other_variants")
     ap.add_argument("--single", action="store_true", help="run only the --weights variant")
     ap.add_argument("--partitions", type=int, default=4096, help="partitions per GPU")
     ap.add_argument("--qubits", type=int, default=1024)
@@ -193,16 +193,26 @@ def main():
     cpu_sample = A[:64, :, :Q].cpu().numpy() if (world == 1 and not args.no_cpu) else None
     alg_bytes = B * ir.T * Q + 4 * ir.nE + 4 * (ir.T + 1) + 8 * B + 8 * C * C
 
-    def run_variant(weights):
-        """Times args.steps passes of the cost path with one weight setting; returns the result block."""
+    def run_variant(weights, table="packed"):
+        """Times args.steps passes of the cost path with one weight setting and one form of the distance
+        table ("packed": what the library chooses; "table": look-ups even when a closed form exists)."""
         random.seed(weight_seed)
         wr = (1.0, 3.0) if weights == "uniform" else (2.0, 2.0)
         arch = multicore(CX, CY, ncm_qubits=4, ncp_qubits=cap, edge_weight_range=wr, network_type="mesh")
         nodes, eu, ev, w = graph_tables(arch.network)
         D = apsp(len(nodes), eu, ev, w)
         dt = DistanceTable(D, dev)
+        closed = table == "packed" and dt.kind == QP_DT_U16 and bool(dt.grid.valid)
+        if dt.kind == QP_DT_U16:
+            how = ("none: closed-form grid metric (v_sad_u8 on packed core ids), verified against the matrix"
+                   if closed else "uint16, LDS-resident")
+            kname = "k_cost_v3_row<u16, grid>" if closed else "k_cost_v3_row<u16, lds256>"
+        elif C * C * 8 <= 128 * 1024:
+            how, kname = "f64, LDS-resident", "k_cost_v3_row<f64, lds>"
+        else:
+            how, kname = "f64, 512 KB: LDS-resident in 4 bands of source cores, one pass per band", "k_cost_v3_row<f64, band> x4"
         for _ in range(args.warmup):
-            eng.cost_v3(dc, dt, A, out=out)
+            eng.cost_v3(dc, dt, A, out=out, table=table)
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
@@ -213,7 +223,7 @@ def main():
         t0 = time.perf_counter()
         ev0.record(stream)
         for _ in range(args.steps):
-            eng.cost_v3(dc, dt, A, out=out)
+            eng.cost_v3(dc, dt, A, out=out, table=table)
         ev1.record(stream)
         torch.cuda.synchronize(dev)
         if world > 1:
@@ -237,19 +247,20 @@ def main():
         achieved = alg_bytes / (dev_ms * 1e-3) / 1e9
         return {"weights": f"{weights} {wr}", "value": world * B * ir.T * args.steps / wall, "unit": "evals/s",
                 "ms_per_step": wall / args.steps * 1e3,
-                "dtype": "u16 table / u32 sums" if dt.kind == QP_DT_U16 else "f64",
-                "table": "uint16, LDS-resident" if dt.kind == QP_DT_U16 else
-                         ("f64, LDS-resident" if C * C * 8 <= 128 * 1024 else "f64, 512 KB in L2 (does not fit LDS)"),
+                "dtype": "u8 core ids / u32 sums" if dt.kind == QP_DT_U16 else "f64",
+                "table": how, "_closed": closed,
                 "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_cost_v3_row",
+                             "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kname,
                              "alg_bytes_per_launch": alg_bytes, "kernel_ms": dev_ms},
                 "mean_cost": float(stats[0].item() / stats[1].item()), "min_cost": float(mn.item()),
                 "reduce_ms": reduce_ms, "_D": D, "_kind": dt.kind, "_costs": out.cpu().numpy().copy()}
 
     primary = run_variant(args.weights)
-    secondary = None
+    others = []
     if not args.single:
-        secondary = run_variant("uniform" if args.weights == "integer" else "integer")
+        if primary["_closed"]:
+            others.append(run_variant(args.weights, table="table"))
+        others.append(run_variant("uniform" if args.weights == "integer" else "integer"))
 
     cm = None
     if not args.no_qubo:
@@ -290,14 +301,17 @@ def main():
             with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
                 tr = json.load(f)
             wk = tr["workload"]
-            if (wk["Q"], wk["T"], wk["B"], wk["weights"]) == (Q, ir.T, B, args.weights):
+            if (wk["Q"], wk["T"], wk["B"], wk["weights"], wk.get("closed_form", False)) == \
+                    (Q, ir.T, B, args.weights, primary["_closed"]):
                 res["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
-        if secondary is not None:
-            for k in ("_D", "_kind", "_costs"):
-                secondary.pop(k)
-            res["other_weights"] = secondary
+        primary.pop("_closed")
+        for o in others:
+            for k in ("_D", "_kind", "_costs", "_closed"):
+                o.pop(k)
+        if others:
+            res["other_variants"] = others
         if world == 1 and not args.no_cpu:
             # CPU baseline on this box's host cores: the C restatement of the reference's cost loop
             # (oracle/cost_oracle.c, same left-to-right sums, one core), on a bounded sample of this

@@ -70,19 +70,34 @@ typedef struct QpCircuit {
                                        slice order), -1 = empty (HQA_placer.py:227-237) */
     const int32_t* slice_visit_ptr; /* [T+1] CSR over visits */
     const QpVisit* visits;          /* [nV] */
-    const uint32_t* edges_sched;    /* optional [nE]: u | v << 16 of the same gates, grouped by slice like
-                                       `edges` (slice_edge_ptr applies) but in any order inside a slice; the
-                                       cost kernels read this list, so the host may order it to spread the
-                                       LDS banks that consecutive gates' endpoints fall into */
+    const uint32_t* edges_sched;    /* optional: u | v << 16 of the same gates in the layout qp_schedule_gates
+                                       writes (every slice padded with zero words to a multiple of
+                                       QP_SCHED_CHUNK, QP_SCHED_TAIL zero words after the last slice); the dense
+                                       cost kernels for long rows read this list */
+    const int32_t* sched_ptr;       /* [T+1] start of every slice in edges_sched (required with it) */
 } QpCircuit;
 
 /* Distance table as the kernels consume it. */
 #define QP_DT_F64 0 /* C*C doubles, row = source core */
 #define QP_DT_U16 1 /* C*C uint16: every finite entry is an integer <= 65534 (integer edge weights) */
+/* Closed form of an integer table on a grid of cores (mesh, line, torus with equal integer edge weights):
+ *   x = core & ((1 << xbits) - 1), y = core >> xbits,
+ *   D[a][b] = wx * dx + wy * dy,  dx = |xa - xb|, or min(|xa - xb|, wrap_x - |xa - xb|) when wrap_x != 0
+ * (dy likewise with wrap_y).  Filled by qp_dtable_grid_metric, which accepts a matrix only if every
+ * entry equals the formula; with valid != 0 the dense cost kernel computes distances from core ids and
+ * never reads the table.  No reference counterpart (it always queries the graph, Placer.py:63-76). */
+typedef struct QpGridMetric {
+    int32_t valid;
+    int32_t xbits;
+    uint32_t wx, wy;
+    int32_t wrap_x, wrap_y; /* 0, or the ring length of that dimension (a power of two, 4..128) */
+} QpGridMetric;
+
 typedef struct QpDTable {
     int32_t kind;
     int32_t C;
     const void* table; /* dev, C*C entries, row-major, zero diagonal */
+    QpGridMetric grid; /* all zero when unused; only consulted for QP_DT_U16 */
 } QpDTable;
 
 int qp_version(void);
@@ -123,17 +138,26 @@ int qp_lsap_f64_batch(int32_t n, const int32_t* nr, const int32_t* nc, const dou
 int qp_timeslices(int32_t n_gates, const int32_t* gq0, const int32_t* gq1, int32_t Q, int32_t* order_out,
                   int32_t* slice_ptr_out, int32_t* T_out);
 
-/* Orders the counted gates of every slice for QpCircuit.edges_sched (u | v << 16): runs of 32 gates get
- * endpoints in distinct 4-byte LDS banks where possible.  No reference counterpart (the cost is a sum
- * over a slice's gates; their order is free). */
+/* Lays the counted gates of every slice out for QpCircuit.edges_sched / sched_ptr: words u | v << 16, each
+ * slice padded with zero words (qubit 0 with itself: distance zero) to a multiple of QP_SCHED_CHUNK so that
+ * a wave reads whole chunks without masking, QP_SCHED_TAIL zero words after the last slice so that reading
+ * a few chunks ahead stays inside the buffer.  Inside a slice, runs of 32 gates get endpoints in distinct
+ * 4-byte LDS banks where possible.  sched_capacity (words) must be at least
+ * sum_t roundup(E_t, QP_SCHED_CHUNK) + QP_SCHED_TAIL.  No reference counterpart (the cost is a sum over a
+ * slice's gates; their order is free). */
+#define QP_SCHED_CHUNK 64
+#define QP_SCHED_TAIL 512
 int qp_schedule_gates(int32_t T, const int32_t* slice_edge_ptr, const uint16_t* eu, const uint16_t* ev,
-                      uint32_t* sched_out);
+                      int32_t* sched_ptr_out /* [T+1] */, uint32_t* sched_out, int64_t sched_capacity);
 
 /* Chooses the device representation of a host distance matrix and writes it into a host staging
  * buffer the caller then copies to the device (C*C*8 bytes is always enough).  The diagonal is
  * forced to 0 (the reference never adds a term for equal cores).  Returns the kind in *kind_out. */
 int qp_dtable_pack(const double* D_host, int32_t C, void* staging /* host */, size_t staging_bytes,
                    int32_t* kind_out, size_t* bytes_out);
+
+/* Tests whether a host distance matrix is a grid metric (see QpGridMetric); *out is zeroed when not. */
+int qp_dtable_grid_metric(const double* D_host, int32_t C, QpGridMetric* out);
 
 /* ---------------------------------------------------------------- device: cost evaluation */
 

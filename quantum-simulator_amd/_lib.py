@@ -14,16 +14,22 @@ QP_DT_F64, QP_DT_U16 = 0, 1
 QP_V2, QP_V1, QP_V4 = 0, 1, 2
 QP_CM_HQA, QP_CM_TRHQA, QP_CM_GTRHQA = 0, 1, 2
 QP_ABSENT = 0xFF
+QP_SCHED_CHUNK, QP_SCHED_TAIL = 64, 512
 
 
 class QpCircuit(C.Structure):
     _fields_ = [("Q", C.c_int32), ("T", C.c_int32), ("nE", C.c_int32), ("nV", C.c_int32),
                 ("slice_edge_ptr", C.c_void_p), ("edges", C.c_void_p), ("lookahead", C.c_void_p),
-                ("slice_visit_ptr", C.c_void_p), ("visits", C.c_void_p), ("edges_sched", C.c_void_p)]
+                ("slice_visit_ptr", C.c_void_p), ("visits", C.c_void_p), ("edges_sched", C.c_void_p), ("sched_ptr", C.c_void_p)]
+
+
+class QpGridMetric(C.Structure):
+    _fields_ = [("valid", C.c_int32), ("xbits", C.c_int32), ("wx", C.c_uint32), ("wy", C.c_uint32),
+                ("wrap_x", C.c_int32), ("wrap_y", C.c_int32)]
 
 
 class QpDTable(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("C", C.c_int32), ("table", C.c_void_p)]
+    _fields_ = [("kind", C.c_int32), ("C", C.c_int32), ("table", C.c_void_p), ("grid", QpGridMetric)]
 
 
 class QpQuboSeg(C.Structure):
@@ -61,9 +67,11 @@ EXPORTS = {
                                     C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]),
     "qp_timeslices": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                 C.POINTER(C.c_int32)]),
-    "qp_schedule_gates": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "qp_schedule_gates": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_int64]),
     "qp_dtable_pack": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.POINTER(C.c_int32),
                                  C.POINTER(C.c_size_t)]),
+    "qp_dtable_grid_metric": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(QpGridMetric)]),
     "qp_slice_cost_workspace": (C.c_size_t, [C.c_int32, C.c_int64]),
     "qp_slice_cost_v3": (C.c_int, [C.POINTER(QpCircuit), C.POINTER(QpDTable), C.c_void_p, C.c_int64, C.c_int32,
                                    C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

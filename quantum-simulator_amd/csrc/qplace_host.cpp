@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <limits>
@@ -327,6 +328,53 @@ extern "C" int qp_dtable_pack(const double* D, int32_t C, void* staging, size_t 
     return QP_OK;
 }
 
+extern "C" int qp_dtable_grid_metric(const double* D, int32_t C, QpGridMetric* out) {
+    if (!D || !out || C <= 0 || C > 256) return qp::fail(QP_EINVAL, "qp_dtable_grid_metric: bad argument");
+    *out = QpGridMetric{};
+    const size_t n = (size_t)C * C;
+    for (size_t k = 0; k < n; ++k) {
+        if (k / C == k % C) continue;
+        const double x = D[k];
+        if (!(std::isfinite(x) && x >= 0.0 && x <= 65534.0 && x == std::floor(x))) return QP_OK;
+    }
+    if (C == 1) return QP_OK;
+    auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+    for (int xbits = 0; xbits <= 8; ++xbits) {
+        const int W = 1 << xbits;
+        if (xbits > 0 && (W >> 1) >= C) break;  // x already covers every core id at the previous width
+        const int H = (C + W - 1) / W;
+        const double wx = W > 1 ? D[1] : 0.0;                   // D[0][1]
+        const double wy = C > W ? D[(size_t)W] : 0.0;           // D[0][W]
+        for (int wrap = 0; wrap < 4; ++wrap) {
+            const bool wrx = wrap & 1, wry = wrap & 2;
+            if (wrx && !(W >= 4 && W <= 128 && C >= W)) continue;
+            if (wry && !(H >= 4 && H <= 128 && pow2(H) && C == W * H)) continue;
+            bool ok = true;
+            for (int a = 0; a < C && ok; ++a)
+                for (int b = 0; b < C; ++b) {
+                    if (a == b) continue;
+                    int dx = std::abs((a & (W - 1)) - (b & (W - 1))), dy = std::abs((a >> xbits) - (b >> xbits));
+                    if (wrx) dx = std::min(dx, W - dx);
+                    if (wry) dy = std::min(dy, H - dy);
+                    if (D[(size_t)a * C + b] != wx * dx + wy * dy) {
+                        ok = false;
+                        break;
+                    }
+                }
+            if (ok) {
+                out->valid = 1;
+                out->xbits = xbits;
+                out->wx = (uint32_t)wx;
+                out->wy = (uint32_t)wy;
+                out->wrap_x = wrx ? W : 0;
+                out->wrap_y = wry ? H : 0;
+                return QP_OK;
+            }
+        }
+    }
+    return QP_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Timeslicing (ASAP layering with the reference's within-slice order) and gate scheduling
 // ------------------------------------------------------------------------------------------------
@@ -407,15 +455,23 @@ extern "C" int qp_timeslices(int32_t n_gates, const int32_t* gq0, const int32_t*
 }
 
 extern "C" int qp_schedule_gates(int32_t T, const int32_t* slice_edge_ptr, const uint16_t* eu, const uint16_t* ev,
-                                 uint32_t* sched_out) {
-    if (T < 0 || !slice_edge_ptr || (slice_edge_ptr[T] > 0 && (!eu || !ev || !sched_out)))
+                                 int32_t* sched_ptr_out, uint32_t* sched_out, int64_t sched_capacity) {
+    if (T < 0 || !slice_edge_ptr || !sched_ptr_out || !sched_out || (slice_edge_ptr[T] > 0 && (!eu || !ev)))
         return qp::fail(QP_EINVAL, "qp_schedule_gates: bad argument");
+    int64_t need = QP_SCHED_TAIL;
+    for (int32_t t = 0; t < T; ++t)
+        need += (int64_t)(slice_edge_ptr[t + 1] - slice_edge_ptr[t] + QP_SCHED_CHUNK - 1) / QP_SCHED_CHUNK * QP_SCHED_CHUNK;
+    if (sched_capacity < need || need > std::numeric_limits<int32_t>::max())
+        return qp::fail(QP_ENOSPC, "qp_schedule_gates: needs room for %lld words", (long long)need);
+    std::fill(sched_out, sched_out + need, 0u);
+    sched_ptr_out[0] = 0;
     std::vector<int32_t> pool, rest, group;
     for (int32_t t = 0; t < T; ++t) {
         const int32_t a = slice_edge_ptr[t], b = slice_edge_ptr[t + 1];
         pool.clear();
         for (int32_t e = a; e < b; ++e) pool.push_back(e);
-        int32_t w = a;
+        int32_t w = sched_ptr_out[t];
+        sched_ptr_out[t + 1] = w + (b - a + QP_SCHED_CHUNK - 1) / QP_SCHED_CHUNK * QP_SCHED_CHUNK;
         while (!pool.empty()) {
             uint32_t used_u = 0, used_v = 0;
             group.clear();

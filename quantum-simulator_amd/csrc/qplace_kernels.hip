@@ -76,6 +76,7 @@ constexpr int kTabGlobal = 2;  // device memory (L2-resident), row pitch C
 constexpr int kTabLdsBand = 3; // LDS holds rows [band_lo, band_lo + band_rows) at pitch 256 plus one zero entry;
                                // pairs whose source core is outside the band read the zero entry, and the
                                // launcher runs one pass per band (for fp64 tables too big for LDS)
+constexpr int kTabGrid = 4;    // no table: the distance is a grid metric computed from the two core ids
 
 // ------------------------------------------------------------------------------------------------
 // Cost V3: dense partitions, HQA-family definition.
@@ -99,13 +100,44 @@ struct V3Args {
     const int32_t* sep;
     const QpEdge* edges;
     const uint32_t* edges_sched;
+    const int32_t* sptr;
     const void* table;
     double* partial;
     int64_t B, nitems;
     int32_t T, Tp, ldq, Q, C, rows_per_item, G, lpr;
     uint32_t table_bytes;
     int32_t band_lo, band_rows;
+    // grid metric (kTabGrid): byte-replicated masks of the x and y fields of a core id, the shift that
+    // brings y down, half the ring length per byte for a dimension that wraps (0 = does not wrap), weights
+    uint32_t gxm, gym, gxb, ghalfx, ghalfy, gwx, gwy;
+    uint32_t gyi;  // gym << gxb: the y field where it sits in a core id
 };
+
+// Sums of per-byte coordinate distances of four core pairs (from, to packed four to a dword) under a
+// grid metric, accumulated with v_sad_u8.  A dimension that wraps has ring length W = 2 * half, a power
+// of two <= 128: d = (from - to) mod W per byte (bit 7 guards the borrow), ring distance = half - |d - half|;
+// the caller adds 4 * half per call and subtracts what accumulates here.
+struct GridAcc {
+    uint32_t x = 0, y = 0, calls = 0;
+    __device__ inline void add4(const V3Args& p, uint32_t from, uint32_t to) {
+        const uint32_t fx = from & p.gxm, tx = to & p.gxm;
+        const uint32_t fy = (from >> p.gxb) & p.gym, ty = (to >> p.gxb) & p.gym;
+        if (p.ghalfx) x = __builtin_amdgcn_sad_u8(((fx | 0x80808080u) - tx) & p.gxm, p.ghalfx, x);
+        else x = __builtin_amdgcn_sad_u8(fx, tx, x);
+        if (p.ghalfy) y = __builtin_amdgcn_sad_u8(((fy | 0x80808080u) - ty) & p.gym, p.ghalfy, y);
+        else y = __builtin_amdgcn_sad_u8(fy, ty, y);
+        ++calls;
+    }
+    // weighted total over the wave (exact: everything is an integer far below 2^53)
+    __device__ inline double total(const V3Args& p) const;
+};
+
+__device__ inline double GridAcc::total(const V3Args& p) const {
+    const double n = wave_sum(calls), sx = wave_sum(x), sy = wave_sum(y);
+    const double dx = p.ghalfx ? n * (double)(4u * (p.ghalfx & 0xFFu)) - sx : sx;
+    const double dy = p.ghalfy ? n * (double)(4u * (p.ghalfy & 0xFFu)) - sy : sy;
+    return (double)p.gwx * dx + (double)p.gwy * dy;
+}
 
 template <int KIND, int TABMODE>
 __global__ __launch_bounds__(kV3Threads) void k_cost_v3(V3Args p) {
@@ -168,6 +200,7 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3(V3Args p) {
         const uint8_t* base = p.A + (size_t)b * p.Tp * ldq;
         const int ngroups = (r1 - r0 + G - 1) / G;
         Acc acc = 0;
+        GridAcc gacc;
 
         auto fetch = [&](int g) -> uint4 {
             const int rg = r0 + g * G;
@@ -210,22 +243,32 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3(V3Args p) {
                 const uint32_t c1 = mv ? cur.y & keep[1] : 0u, p1 = mv ? prv.y & keep[1] : 0u;
                 const uint32_t c2 = mv ? cur.z & keep[2] : 0u, p2 = mv ? prv.z & keep[2] : 0u;
                 const uint32_t c3 = mv ? cur.w & keep[3] : 0u, p3 = mv ? prv.w & keep[3] : 0u;
-                const bool moved = ((c0 ^ p0) | (c1 ^ p1) | (c2 ^ p2) | (c3 ^ p3)) != 0;
-                if (__builtin_amdgcn_ballot_w64(moved) != 0)
-                    acc += (four(p0, c0) + four(p1, c1)) + (four(p2, c2) + four(p3, c3));
+                if constexpr (TABMODE == kTabGrid) {
+                    gacc.add4(p, p0, c0);
+                    gacc.add4(p, p1, c1);
+                    gacc.add4(p, p2, c2);
+                    gacc.add4(p, p3, c3);
+                } else {
+                    const bool moved = ((c0 ^ p0) | (c1 ^ p1) | (c2 ^ p2) | (c3 ^ p3)) != 0;
+                    if (__builtin_amdgcn_ballot_w64(moved) != 0)
+                        acc += (four(p0, c0) + four(p1, c1)) + (four(p2, c2) + four(p3, c3));
+                }
                 // counted two-qubit gates of these slices
                 const int e0 = __builtin_amdgcn_readfirstlane(p.sep[rg]);
                 const int e1 = __builtin_amdgcn_readfirstlane(p.sep[min(rg + G, r1)]);
                 for (int e = e0 + lane; e < e1; e += kWave) {
                     const QpEdge ed = p.edges[e];
                     const uint8_t* rowp = strip + ldq + (ed.t - rg) * ldq;
-                    acc += pair_at(rowp[ed.u], rowp[ed.v]);
+                    if constexpr (TABMODE == kTabGrid) gacc.add4(p, rowp[ed.u], rowp[ed.v]);
+                    else acc += pair_at(rowp[ed.u], rowp[ed.v]);
                 }
                 // the last row of the group becomes "the row before" of the next group
                 if (lane_on && lrow == G - 1) *reinterpret_cast<uint4*>(strip + lq0) = cur;
             }
         }
-        const double s = wave_sum(acc);
+        double s;
+        if constexpr (TABMODE == kTabGrid) s = gacc.total(p);
+        else s = wave_sum(acc);
         if (lane == 0) p.partial[it] = s;
     }
 }
@@ -234,10 +277,11 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3(V3Args p) {
 // stays in registers (no LDS round trip), the LDS strip holds only the current row for the edge
 // endpoint gathers, and each row's first kRowEdgeChunks*64 gates are loaded together with the row,
 // kV3Ahead rows ahead, so that vector-memory results are consumed in the order they were requested.
-// Gates come from the scheduled list (u | v << 16), whose order inside a slice the host may choose.
+// Gates come from the scheduled list (u | v << 16, every slice padded to whole 64-gate chunks with
+// zero words, readable a few chunks past its end), so chunks are read and used without lane masks.
 constexpr int kRowEdgeChunks = 4;
 
-template <int KIND, int TABMODE>
+template <int KIND, int TABMODE, int AHEAD = kV3Ahead>
 __global__ __launch_bounds__(kV3Threads) void k_cost_v3_row(V3Args p) {
     extern __shared__ __align__(16) uint8_t smem[];
     using E = typename Tab<KIND>::elem;
@@ -319,46 +363,45 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_row(V3Args p) {
         auto fetch_row = [&](int row) -> uint4 {
             return *reinterpret_cast<const uint4*>(base + (size_t)min(row, r1 - 1) * ldq + lane16);
         };
-        // gate `lane` of chunk c of the row (whatever word sits there if the row has fewer gates: the
-        // consumer masks it, so nothing here waits on a loaded value)
-        const int last_gate = p.sep[p.T] - 1;
+        // gate `lane` of chunk c of the row (a later slice's gates or padding if the row has fewer
+        // chunks: the consumer skips those, so nothing here waits on a loaded value)
         auto fetch_gate = [&](int row, int c) -> uint32_t {
-            const int e = p.sep[min(row, r1 - 1)] + c * kWave + lane;
-            return p.edges_sched[min(e, last_gate)];
+            return p.edges_sched[p.sptr[min(row, r1 - 1)] + c * kWave + lane];
         };
 
         uint4 prv = make_uint4(0, 0, 0, 0);
         if (r0 >= 1 && lane_on) prv = *reinterpret_cast<const uint4*>(base + (size_t)(r0 - 1) * ldq + lane * 16);
-        uint4 ring[kV3Ahead];
-        uint32_t gring[kV3Ahead][kRowEdgeChunks];
+        uint4 ring[AHEAD];
+        uint32_t gring[AHEAD][kRowEdgeChunks];
 #pragma unroll
-        for (int k = 0; k < kV3Ahead; ++k) {
+        for (int k = 0; k < AHEAD; ++k) {
             ring[k] = fetch_row(r0 + k);
 #pragma unroll
             for (int c = 0; c < kRowEdgeChunks; ++c) gring[k][c] = fetch_gate(r0 + k, c);
         }
 
-        for (int g0 = r0; g0 < r1; g0 += kV3Ahead) {
+        for (int g0 = r0; g0 < r1; g0 += AHEAD) {
 #pragma unroll
-            for (int k = 0; k < kV3Ahead; ++k) {
+            for (int k = 0; k < AHEAD; ++k) {
                 const int row = g0 + k;
                 if (row >= r1) break;
                 const uint4 cur = ring[k];
                 uint32_t gates[kRowEdgeChunks];
 #pragma unroll
                 for (int c = 0; c < kRowEdgeChunks; ++c) gates[c] = gring[k][c];
-                ring[k] = fetch_row(row + kV3Ahead);
+                ring[k] = fetch_row(row + AHEAD);
 #pragma unroll
-                for (int c = 0; c < kRowEdgeChunks; ++c) gring[k][c] = fetch_gate(row + kV3Ahead, c);
+                for (int c = 0; c < kRowEdgeChunks; ++c) gring[k][c] = fetch_gate(row + AHEAD, c);
 
                 if (lane_on) *reinterpret_cast<uint4*>(strip + lane * 16) = cur;
                 // endpoint gathers of the row's gates first, so the movement look-ups overlap them; a
-                // lane without a gate in a chunk uses (0, 0): one qubit twice, distance zero
-                const int ngates = p.sep[row + 1] - p.sep[row];
+                // chunk the row does not have uses (0, 0): one qubit twice, distance zero
+                const int s0 = p.sptr[row];
+                const int nch = (p.sptr[row + 1] - s0) / kWave;
                 uint32_t au[kRowEdgeChunks], av[kRowEdgeChunks];
 #pragma unroll
                 for (int c = 0; c < kRowEdgeChunks; ++c) {
-                    const uint32_t g = (c * kWave + lane < ngates) ? gates[c] : 0u;
+                    const uint32_t g = c < nch ? gates[c] : 0u;
                     au[c] = strip[g & 0xFFFFu];
                     av[c] = strip[g >> 16];
                 }
@@ -376,15 +419,160 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_row(V3Args p) {
                     for (int c = 0; c < kRowEdgeChunks; ++c) s += pair_at(au[c], av[c]);
                     acc += s;
                 }
-                const int e1 = __builtin_amdgcn_readfirstlane(p.sep[row + 1]);
-                for (int e = __builtin_amdgcn_readfirstlane(p.sep[row]) + kRowEdgeChunks * kWave + lane; e < e1; e += kWave) {
-                    const uint32_t g = p.edges_sched[e];
+                for (int c = kRowEdgeChunks; c < nch; ++c) {
+                    const uint32_t g = p.edges_sched[s0 + c * kWave + lane];
                     acc += pair_at(strip[g & 0xFFFFu], strip[g >> 16]);
                 }
                 prv = cur;
             }
         }
         const double s = wave_sum(acc);
+        if (lane == 0) p.partial[it] = s;
+    }
+}
+
+// Rows longer than 512 bytes under a grid metric (no table).  Written for a low vector-instruction
+// count, which is what bounds it once nothing is looked up: row and gate loads use wave-uniform base
+// pointers plus a fixed per-lane offset; strips sit at a pitch of 1024 bytes; the previous row is
+// carried as its masked x and y fields, with the y field left where it sits in the byte (the sum comes
+// out scaled by 2^xbits and is scaled back once per item); the "qubit exists" byte masks of a ragged
+// row are folded into the field masks.  WRAP (some dimension is a ring) takes the general per-byte path.
+constexpr int kGridStrip = 1024;
+
+template <bool WRAP, int AHEAD>
+__global__ __launch_bounds__(kV3Threads) void k_cost_v3_grid_row(V3Args p) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    static_assert(kRowEdgeChunks == 4, "four gate chunks fill one dword of endpoints");
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int ldq = p.ldq;
+    uint8_t* strip = smem + wave * kGridStrip;
+    const bool lane_on = lane * 16 < ldq;
+    const int lane16 = lane_on ? lane * 16 : 0;
+    const int nvalid_row = min(16, max(0, p.Q - lane * 16));
+    uint32_t keep[4], kx[4], ky[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const int nb = min(4, max(0, nvalid_row - 4 * w));
+        keep[w] = nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u);
+        kx[w] = keep[w] & p.gxm;
+        ky[w] = keep[w] & p.gyi;
+    }
+    const uint32_t* sched_lane = p.edges_sched + lane;
+
+    for (int64_t it = (int64_t)blockIdx.x * kV3Waves + wave; it < p.nitems; it += (int64_t)gridDim.x * kV3Waves) {
+        const int chunk = (int)(it / p.B);
+        const int64_t b = it - (int64_t)chunk * p.B;
+        const int r0 = chunk * p.rows_per_item;
+        const int r1 = min(p.T, r0 + p.rows_per_item);
+        const uint8_t* base = p.A + (size_t)b * p.Tp * ldq;
+        uint32_t ax = 0, ay = 0;
+        GridAcc gacc;
+
+        auto fetch_row = [&](int row) -> uint4 {
+            const uint8_t* rp = base + (size_t)min(row, r1 - 1) * ldq;  // wave-uniform
+            return *reinterpret_cast<const uint4*>(rp + lane16);
+        };
+        auto fetch_gate = [&](int row, int c) -> uint32_t {
+            const uint32_t* gp = sched_lane + p.sptr[min(row, r1 - 1)];  // wave-uniform + lane
+            return gp[c * kWave];
+        };
+
+        uint4 prv = make_uint4(0, 0, 0, 0);
+        if (r0 >= 1) prv = fetch_row(r0 - 1);
+        // non-WRAP: masked x and y fields of the previous row; WRAP: px is the whole masked row
+        const uint32_t* mx = WRAP ? keep : kx;
+        uint32_t px[4] = {prv.x & mx[0], prv.y & mx[1], prv.z & mx[2], prv.w & mx[3]};
+        uint32_t py[4] = {prv.x & ky[0], prv.y & ky[1], prv.z & ky[2], prv.w & ky[3]};
+        uint4 ring[AHEAD];
+        uint32_t gring[AHEAD][kRowEdgeChunks];
+#pragma unroll
+        for (int k = 0; k < AHEAD; ++k) {
+            ring[k] = fetch_row(r0 + k);
+#pragma unroll
+            for (int c = 0; c < kRowEdgeChunks; ++c) gring[k][c] = fetch_gate(r0 + k, c);
+        }
+
+        for (int g0 = r0; g0 < r1; g0 += AHEAD) {
+#pragma unroll
+            for (int k = 0; k < AHEAD; ++k) {
+                const int row = g0 + k;
+                if (row >= r1) break;
+                const uint4 cur = ring[k];
+                uint32_t gates[kRowEdgeChunks];
+#pragma unroll
+                for (int c = 0; c < kRowEdgeChunks; ++c) gates[c] = gring[k][c];
+                ring[k] = fetch_row(row + AHEAD);
+#pragma unroll
+                for (int c = 0; c < kRowEdgeChunks; ++c) gring[k][c] = fetch_gate(row + AHEAD, c);
+
+                if (lane_on) *reinterpret_cast<uint4*>(strip + lane * 16) = cur;
+                const int s0 = p.sptr[row];
+                const int nch = (p.sptr[row + 1] - s0) / kWave;
+                // endpoint gathers of the row's gates; a chunk the row does not have stays (0, 0)
+                uint32_t au[kRowEdgeChunks], av[kRowEdgeChunks];
+#pragma unroll
+                for (int c = 0; c < kRowEdgeChunks; ++c) {
+                    au[c] = 0;
+                    av[c] = 0;
+                    if (c < nch) {
+                        au[c] = strip[gates[c] & 0xFFFFu];
+                        av[c] = strip[gates[c] >> 16];
+                    }
+                }
+                const uint32_t cw[4] = {cur.x, cur.y, cur.z, cur.w};
+                if constexpr (WRAP) {
+                    if (row >= 2) {
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) gacc.add4(p, px[w], cw[w] & keep[w]);
+                    }
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) px[w] = cw[w] & keep[w];  // WRAP carries the whole masked row in px
+                } else {
+                    uint32_t cx[4], cy[4];
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        cx[w] = cw[w] & kx[w];
+                        cy[w] = cw[w] & ky[w];
+                    }
+                    if (row >= 2) {
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) {
+                            ax = __builtin_amdgcn_sad_u8(px[w], cx[w], ax);
+                            ay = __builtin_amdgcn_sad_u8(py[w], cy[w], ay);
+                        }
+                    }
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        px[w] = cx[w];
+                        py[w] = cy[w];
+                    }
+                }
+                {
+                    const uint32_t U = au[0] | au[1] << 8 | au[2] << 16 | au[3] << 24;
+                    const uint32_t V = av[0] | av[1] << 8 | av[2] << 16 | av[3] << 24;
+                    if constexpr (WRAP) {
+                        gacc.add4(p, U, V);
+                    } else {
+                        ax = __builtin_amdgcn_sad_u8(U & p.gxm, V & p.gxm, ax);
+                        ay = __builtin_amdgcn_sad_u8(U & p.gyi, V & p.gyi, ay);
+                    }
+                }
+                for (int c = kRowEdgeChunks; c < nch; ++c) {
+                    const uint32_t g = sched_lane[s0 + c * kWave];
+                    const uint32_t U = strip[g & 0xFFFFu], V = strip[g >> 16];
+                    if constexpr (WRAP) {
+                        gacc.add4(p, U, V);
+                    } else {
+                        ax = __builtin_amdgcn_sad_u8(U & p.gxm, V & p.gxm, ax);
+                        ay = __builtin_amdgcn_sad_u8(U & p.gyi, V & p.gyi, ay);
+                    }
+                }
+            }
+        }
+        double s;
+        if constexpr (WRAP) s = gacc.total(p);
+        else s = (double)p.gwx * wave_sum(ax) + (double)p.gwy * (wave_sum(ay) / (double)(1u << p.gxb));
         if (lane == 0) p.partial[it] = s;
     }
 }
@@ -592,7 +780,13 @@ int device_cus() {
     return n;
 }
 
-int rows_per_item_for(int32_t T, int32_t G) {
+int rows_per_item_for(int32_t T, int32_t G, int64_t B, int cus) {
+    if (G == 1) {
+        // one row per step: long items amortise the pipeline fill at an item's start (the first rows are
+        // waited for with nothing else in flight); keep about 8 items per resident wave for balance
+        const int64_t want = (int64_t)T * B / ((int64_t)cus * kV3Waves * 8);
+        return (int)std::min<int64_t>(256, std::max<int64_t>(32, want));
+    }
     // about 32 rows per item, a multiple of the group size, so the one extra row read per item is ~3%
     int r = std::max(G, (32 / G) * G);
     if (r < kV3Ahead * G && T > kV3Ahead * G) r = kV3Ahead * G;
@@ -639,6 +833,7 @@ extern "C" int qp_slice_cost_v3(const QpCircuit* circ, const QpDTable* dt, const
     p.sep = circ->slice_edge_ptr;
     p.edges = circ->edges;
     p.edges_sched = circ->edges_sched;
+    p.sptr = circ->sched_ptr;
     p.table = dt->table;
     p.B = B;
     p.T = T;
@@ -657,17 +852,19 @@ extern "C" int qp_slice_cost_v3(const QpCircuit* circ, const QpDTable* dt, const
         p.lpr = 0;
         p.G = 1;
     }
-    p.rows_per_item = rows_per_item_for(T, p.G);
+    const int cus = device_cus();
+    p.rows_per_item = rows_per_item_for(T, p.G, B, cus);
+    if (getenv("QP_TUNE_ROWS")) p.rows_per_item = atoi(getenv("QP_TUNE_ROWS"));
     const int32_t nchunks = (T + p.rows_per_item - 1) / p.rows_per_item;
     p.nitems = (int64_t)nchunks * B;
     if (!workspace || workspace_bytes < (size_t)p.nitems * sizeof(double))
         return qp::fail(QP_ENOSPC, "qp_slice_cost_v3: workspace needs %zu bytes", (size_t)p.nitems * sizeof(double));
     p.partial = static_cast<double*>(workspace);
-    const int cus = device_cus();
 
     if (narrow) {
-        const bool rowpath = ldq > 512 && circ->edges_sched != nullptr && circ->nE > 0;
-        const size_t strips = rowpath ? (size_t)kV3Waves * ldq : (size_t)kV3Waves * (p.G + 1) * ldq;
+        const bool rowpath = ldq > 512 && circ->edges_sched != nullptr && circ->sched_ptr != nullptr && circ->nE > 0;
+        const bool gridpath = dt->kind == QP_DT_U16 && dt->grid.valid;
+        const size_t strips = rowpath ? (size_t)kV3Waves * (gridpath ? kGridStrip : ldq) : (size_t)kV3Waves * (p.G + 1) * ldq;
         const size_t tab256 = (size_t)dt->C * 256 * esz;
         int mode = kTabGlobal;
         size_t lds = strips;
@@ -680,6 +877,37 @@ extern "C" int qp_slice_cost_v3(const QpCircuit* circ, const QpDTable* dt, const
         }
         const unsigned grid = (unsigned)std::min<int64_t>(cus, (p.nitems + kV3Waves - 1) / kV3Waves);
         void (*kern)(V3Args) = nullptr;
+        if (gridpath) {
+            // closed-form distances: no table in LDS, so more than one workgroup fits a CU
+            const QpGridMetric& g = dt->grid;
+            if (g.xbits < 0 || g.xbits > 8 || (g.wrap_x && g.wrap_x != (1 << g.xbits)) || g.wrap_x > 128 ||
+                g.wrap_y > 128 || (g.wrap_y & (g.wrap_y - 1)) || (g.wrap_y && (g.wrap_y << g.xbits) != dt->C))
+                return qp::fail(QP_EINVAL, "qp_slice_cost_v3: inconsistent grid metric");
+            const uint32_t rep = 0x01010101u;
+            p.gxb = (uint32_t)g.xbits;
+            p.gxm = ((1u << g.xbits) - 1u) * rep;
+            p.gym = (g.wrap_y ? (uint32_t)(g.wrap_y - 1) : (0xFFu >> g.xbits)) * rep;
+            p.ghalfx = (uint32_t)(g.wrap_x / 2) * rep;
+            p.ghalfy = (uint32_t)(g.wrap_y / 2) * rep;
+            p.gwx = g.wx;
+            p.gwy = g.wy;
+            p.gyi = p.gym << p.gxb;
+            const bool wrap = g.wrap_x || g.wrap_y;
+            const int ahead = getenv("QP_TUNE_AHEAD") ? atoi(getenv("QP_TUNE_AHEAD")) : 3;
+            if (!rowpath) kern = k_cost_v3<QP_DT_U16, kTabGrid>;
+            else if (wrap) kern = k_cost_v3_grid_row<true, 3>;
+            else kern = ahead == 2 ? k_cost_v3_grid_row<false, 2> : ahead == 4 ? k_cost_v3_grid_row<false, 4>
+                      : ahead == 6 ? k_cost_v3_grid_row<false, 6> : k_cost_v3_grid_row<false, 3>;
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)strips));
+            int per_cu = 1;
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), kV3Threads, strips));
+            const unsigned ggrid = (unsigned)std::min<int64_t>((int64_t)cus * std::max(per_cu, 1), (p.nitems + kV3Waves - 1) / kV3Waves);
+            kern<<<ggrid, kV3Threads, strips, stream>>>(p);
+            HIP_TRY(hipGetLastError());
+            k_sum_chunks<<<(unsigned)((B + 255) / 256), 256, 0, stream>>>(p.partial, B, nchunks, out);
+            HIP_TRY(hipGetLastError());
+            return QP_OK;
+        }
         if (rowpath && mode == kTabGlobal && dt->kind == QP_DT_F64) {
             // fp64 table too big for LDS: one pass per band of source cores, each with its band in LDS
             const int band_rows = (int)std::min<size_t>(dt->C, ((size_t)kLdsBytes - strips - 16) / (256 * esz));

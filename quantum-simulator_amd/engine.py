@@ -10,7 +10,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import (QP_ABSENT, QP_CM_GTRHQA, QP_CM_HQA, QP_CM_TRHQA, QP_DT_F64, QP_DT_U16, QP_V1, QP_V2, QP_V4,
-                   QpCircuit, QpDTable, check, lib, ptr)
+                   QpCircuit, QpDTable, QpGridMetric, check, lib, ptr)
 from .timeslices import CircuitIR
 
 
@@ -105,10 +105,11 @@ class DeviceCircuit:
         self._la = _to_dev(ir.lookahead, self.device)
         self._svp = _to_dev(ir.slice_visit_ptr, self.device)
         self._visits = _to_dev(ir.visit_records, self.device)
-        self._sched = _to_dev(ir.scheduled_edges(), self.device)
+        sptr, sched = ir.scheduled_edges()
+        self._sched, self._sched_ptr = _to_dev(sched, self.device), _to_dev(sptr, self.device)
         self.c = QpCircuit(ir.Q, ir.T, ir.nE, ir.nV, self._sep.data_ptr(), self._edges.data_ptr(),
                            self._la.data_ptr(), self._svp.data_ptr(), self._visits.data_ptr(),
-                           self._sched.data_ptr())
+                           self._sched.data_ptr(), self._sched_ptr.data_ptr())
         self.ldq = (ir.Q + 15) // 16 * 16
 
     @property
@@ -133,7 +134,13 @@ class DistanceTable:
         self.kind = kind.value
         padded = (nbytes.value + 15) // 16 * 16
         self._packed = torch.from_numpy(staging[:padded].copy()).to(self.device)
-        self.packed = QpDTable(self.kind, self.C, self._packed.data_ptr())
+        # "table": always looked up; "packed": additionally carries the closed form of a grid metric
+        # when the matrix is one, and the dense cost kernel then computes distances from core ids
+        self.table_only = QpDTable(self.kind, self.C, self._packed.data_ptr())
+        self.grid = QpGridMetric()
+        if self.kind == QP_DT_U16:
+            check(lib().qp_dtable_grid_metric(ptr(self.D), self.C, C.byref(self.grid)))
+        self.packed = QpDTable(self.kind, self.C, self._packed.data_ptr(), self.grid)
         if self.kind == QP_DT_F64:
             self._f64 = self._packed
         else:
@@ -187,7 +194,7 @@ class Engine:
         if out is None:
             out = torch.empty(B, dtype=torch.float64, device=self.device)
         ws = self._workspace(lib().qp_slice_cost_workspace(dc.ir.T, B))
-        tab = dt.packed if table == "packed" else dt.f64
+        tab = {"packed": dt.packed, "table": dt.table_only, "f64": dt.f64}[table]
         check(lib().qp_slice_cost_v3(C.byref(dc.c), C.byref(tab), A.data_ptr(), B, Tp, ldq, out.data_ptr(),
                                      ws.data_ptr(), ws.numel(), _stream_ptr(self.device)))
         return out

@@ -274,21 +274,22 @@ class CircuitIR:
         self.visit_records = rec
         self.slice_visit_ptr = np.asarray(ptr, np.int32)
 
-    def scheduled_edges(self, spread_banks=True) -> np.ndarray:
-        """uint32 (u | v << 16) per counted gate, grouped by slice, ordered inside each slice so that
-        32 consecutive gates (the lanes that share LDS cycles) have their u endpoints, and as far as
-        possible their v endpoints, in different 4-byte LDS banks of the row strip.  The cost is a sum
-        over the slice's gates, so their order is free."""
-        out = (self.edge_u.astype(np.uint32) | (self.edge_v.astype(np.uint32) << 16))
-        if not spread_banks or self.Q <= 64 or self.nE == 0:
-            return out
+    def scheduled_edges(self):
+        """(sched_ptr[T+1], words): the counted gates as uint32 (u | v << 16) in the padded per-slice
+        layout the dense cost kernels read (see qp_schedule_gates).  Inside a slice 32 consecutive
+        gates (the lanes that share LDS cycles) get their endpoints in different 4-byte LDS banks of
+        the row strip where possible; the cost is a sum over the slice's gates, so their order is free."""
         from . import _lib
         eu = np.ascontiguousarray(self.edge_u, np.uint16)
         ev = np.ascontiguousarray(self.edge_v, np.uint16)
         sep = np.ascontiguousarray(self.slice_edge_ptr, np.int32)
-        sched = np.empty(self.nE, np.uint32)
-        _lib.check(_lib.lib().qp_schedule_gates(self.T, _lib.ptr(sep), _lib.ptr(eu), _lib.ptr(ev), _lib.ptr(sched)))
-        return sched
+        ch = _lib.QP_SCHED_CHUNK
+        n = int(((np.diff(sep.astype(np.int64)) + ch - 1) // ch * ch).sum()) + _lib.QP_SCHED_TAIL
+        sched = np.empty(n, np.uint32)
+        sptr = np.empty(self.T + 1, np.int32)
+        _lib.check(_lib.lib().qp_schedule_gates(self.T, _lib.ptr(sep), _lib.ptr(eu), _lib.ptr(ev), _lib.ptr(sptr),
+                                                _lib.ptr(sched), n))
+        return sptr, sched
 
     # -- helpers ----------------------------------------------------------------------------------
     def slice_ops(self, t: int):

@@ -55,7 +55,7 @@ def test_cost_v3_golden(gpu, name):
             continue
         A = torch.from_numpy(_pad(gc.part(p), dc.ldq)[None].copy()).to(dev)
         terms = O.cost_v3_terms(gc.slices, gc.gate_q, gc.gate_mr, gc.part(p).tolist(), gc.D.tolist())
-        for table in ("packed", "f64"):
+        for table in ("packed", "table", "f64"):
             got = float(eng.cost_v3(dc, dt, A, table=table).cpu()[0])
             assert _close(got, gc.cost(p), exact, len(terms)), (p, table, got, gc.cost(p))
             # against the correctly rounded sum the kernel is inside 1e-12 however many terms there are
@@ -140,6 +140,45 @@ def test_cost_v3_random(gpu, Q, T, C, B, integer):
     for b in range(B):
         want = O.cost_v3(ir.slices, ir.gate_q, ir.gate_mr, A[b, :, :Q].tolist(), Dl)
         assert _close(got[b], want, integer), (b, got[b], want)
+
+
+GRIDS = [  # topology, nx, ny, integer edge weight, closed form expected
+    ("mesh", 4, 4, 2.0, True), ("mesh", 2, 8, 3.0, True), ("mesh", 16, 16, 2.0, True), ("mesh", 3, 4, 2.0, True),
+    ("mesh", 4, 3, 2.0, False), ("mesh", 8, 2, 5.0, True), ("mesh", 2, 1, 1.0, True), ("line", 7, 1, 1.0, True),
+    ("line", 200, 1, 3.0, True), ("torus", 8, 8, 2.0, True), ("torus", 4, 16, 1.0, True), ("torus", 16, 16, 1.0, True),
+    ("torus", 3, 8, 1.0, False), ("star", 9, 1, 2.0, False), ("all_to_all", 4, 4, 1.0, False),
+]
+
+
+@pytest.mark.parametrize("topo,nx,ny,wt,closed", GRIDS)
+@pytest.mark.parametrize("Q,T", [(40, 23), (600, 9), (1024, 40), (1021, 5)])
+def test_cost_v3_grid_metric(gpu, topo, nx, ny, wt, closed, Q, T):
+    """Integer-weight meshes, lines and tori: the kernel that computes distances from core ids, the
+    kernel that looks them up in the uint16 table, and the oracle agree exactly."""
+    torch, engine, eng, dev = gpu
+    from quantum_simulator_amd import layered_gate_arrays
+    from quantum_simulator_amd.multicore import multicore
+    from quantum_simulator_amd.timeslices import CircuitIR
+    arch = multicore(nx, ny, ncp_qubits=4, edge_weight_range=(wt, wt), network_type=topo)
+    dt = engine.DistanceTable.from_network(arch.network, dev)
+    assert dt.kind == engine.QP_DT_U16
+    assert bool(dt.grid.valid) == closed, (dt.grid.valid, dt.grid.xbits, dt.grid.wrap_x, dt.grid.wrap_y)
+    C = dt.C
+    rng = np.random.default_rng(Q + T + C)
+    q0, q1, _ = layered_gate_arrays(Q, T, 0.7, seed=Q + C)
+    keep = rng.random(len(q0)) > 0.2
+    ir = CircuitIR.from_gate_tables(Q, q0[keep], q1[keep])
+    dc = engine.DeviceCircuit(ir, dev)
+    B = 3
+    A = rng.integers(0, C, size=(B, ir.T, dc.ldq), dtype=np.uint8)
+    A[:, :, Q:] = rng.integers(0, 256, size=(B, ir.T, dc.ldq - Q), dtype=np.uint8)
+    Ad = torch.from_numpy(A).to(dev)
+    got = eng.cost_v3(dc, dt, Ad).cpu().numpy()
+    tab = eng.cost_v3(dc, dt, Ad, table="table").cpu().numpy()
+    assert got.tobytes() == tab.tobytes()
+    Dl = dt.D.tolist()
+    want = O.cost_v3(ir.slices, ir.gate_q, ir.gate_mr, A[0, :, :Q].tolist(), Dl)
+    assert got[0] == want
 
 
 @pytest.mark.parametrize("Q,T,C,B,integer", [s for s in SHAPES if s[2] <= 255][:10])
@@ -263,6 +302,9 @@ def test_cost_v3_full_size_against_c_oracle(gpu, integer):
         move = rng.random((B, Q)) < pm
         A[:, t] = np.where(move, rng.integers(0, 256, size=(B, Q)), A[:, t - 1])
     got = eng.cost_v3(dc, dt, torch.from_numpy(A).to(dev)).cpu().numpy()
+    if integer:  # closed-form distances (the default for this table) and table look-ups
+        assert dt.grid.valid
+        assert got.tobytes() == eng.cost_v3(dc, dt, torch.from_numpy(A).to(dev), table="table").cpu().numpy().tobytes()
     gt = c_oracle.GateTables(ir.slices, ir.gate_q, ir.gate_mr)
     nterms = ir.nE + T * Q
     for b in range(B):

@@ -196,17 +196,70 @@ def test_native_timeslices_random_vs_python_sets():
         native_slices(4, np.array([0], np.int32), np.array([0], np.int32))  # both operands the same qubit
 
 
-def test_scheduled_gates_are_a_per_slice_permutation():
+def test_scheduled_gates_are_a_padded_per_slice_permutation():
     from quantum_simulator_amd import layered_gate_arrays
     q0, q1, _ = layered_gate_arrays(300, 12, 0.5, seed=8)
-    ir = CircuitIR.from_gate_tables(300, q0, q1)
-    plain, sched = ir.scheduled_edges(False), ir.scheduled_edges(True)
-    assert plain.tolist() == (ir.edge_u.astype(np.uint32) | (ir.edge_v.astype(np.uint32) << 16)).tolist()
+    keep = np.random.default_rng(1).random(len(q0)) > 0.3
+    ir = CircuitIR.from_gate_tables(300, q0[keep], q1[keep])
+    plain = ir.edge_u.astype(np.uint32) | (ir.edge_v.astype(np.uint32) << 16)
+    sptr, sched = ir.scheduled_edges()
+    ch, tail = _lib.QP_SCHED_CHUNK, _lib.QP_SCHED_TAIL
+    assert sptr[0] == 0 and len(sched) == sptr[-1] + tail and not sched[sptr[-1]:].any()
     worse = 0
     for t in range(ir.T):
         a, b = ir.slice_edge_ptr[t], ir.slice_edge_ptr[t + 1]
-        assert sorted(plain[a:b].tolist()) == sorted(sched[a:b].tolist())
-        for arr, sign in ((plain, 1), (sched, -1)):
-            banks = ((arr[a:a + 32] & 0xFFFF) >> 2) & 31
+        s0, s1 = sptr[t], sptr[t + 1]
+        assert s1 - s0 == (b - a + ch - 1) // ch * ch
+        assert sorted(plain[a:b].tolist()) == sorted(sched[s0:s0 + (b - a)].tolist())
+        assert not sched[s0 + (b - a):s1].any()  # padding: qubit 0 with itself
+        for arr, lo, sign in ((plain, a, 1), (sched, s0, -1)):
+            banks = ((arr[lo:lo + 32] & 0xFFFF) >> 2) & 31
             worse += sign * (32 - len(set(banks.tolist())))
     assert worse > 0, "the schedule should spread the first 32 gates' endpoints over more banks"
+    with pytest.raises(_lib.QplaceError):  # too little room
+        eu, ev = ir.edge_u.astype(np.uint16), ir.edge_v.astype(np.uint16)
+        sep = np.ascontiguousarray(ir.slice_edge_ptr, np.int32)
+        _lib.check(_lib.lib().qp_schedule_gates(ir.T, _lib.ptr(sep), _lib.ptr(eu), _lib.ptr(ev), _lib.ptr(sptr.copy()),
+                                                _lib.ptr(sched), len(sched) - 1))
+
+
+def _grid_metric(D):
+    g = _lib.QpGridMetric()
+    D = np.ascontiguousarray(D, np.float64)
+    _lib.check(_lib.lib().qp_dtable_grid_metric(_lib.ptr(D), D.shape[0], ctypes.byref(g)))
+    return g
+
+
+def test_grid_metric_detection():
+    """A matrix is accepted as a grid metric only if every entry equals the closed form."""
+    import random
+    from quantum_simulator_amd.engine import apsp
+    from quantum_simulator_amd.multicore import multicore, graph_tables
+
+    def table(topo, nx, ny, w):
+        random.seed(3)
+        arch = multicore(nx, ny, ncp_qubits=2, edge_weight_range=w, network_type=topo)
+        nodes, eu, ev, ww = graph_tables(arch.network)
+        return apsp(len(nodes), eu, ev, ww)
+
+    g = _grid_metric(table("mesh", 4, 4, (2.0, 2.0)))
+    assert (g.valid, g.xbits, g.wx, g.wy, g.wrap_x, g.wrap_y) == (1, 2, 2, 2, 0, 0)
+    g = _grid_metric(table("mesh", 16, 16, (2.0, 2.0)))
+    assert (g.valid, g.xbits, g.wx, g.wy) == (1, 4, 2, 2)
+    g = _grid_metric(table("torus", 8, 8, (3.0, 3.0)))
+    assert (g.valid, g.xbits, g.wx, g.wy, g.wrap_x, g.wrap_y) == (1, 3, 3, 3, 8, 8)
+    g = _grid_metric(table("line", 9, 1, (1.0, 1.0)))
+    assert g.valid and g.wrap_x == 0 and g.wrap_y == 0
+    D = table("mesh", 4, 4, (2.0, 2.0))
+    want = np.array([[g2 for g2 in row] for row in D])
+    for bad in (table("mesh", 4, 4, (1.0, 3.0)), table("mesh", 3, 3, (2.0, 2.0)), table("star", 6, 1, (2.0, 2.0)),
+                table("all_to_all", 4, 4, (1.0, 1.0))):
+        assert not _grid_metric(bad).valid
+    D[3, 9] += 1.0  # one entry off the formula
+    assert not _grid_metric(D).valid
+    # the closed form reproduces the matrix it was accepted for
+    g = _grid_metric(want)
+    W = 1 << g.xbits
+    for a in range(16):
+        for b in range(16):
+            assert want[a, b] == g.wx * abs(a % W - b % W) + g.wy * abs(a // W - b // W)

@@ -1,0 +1,56 @@
+"""Sweeps the dense cost kernel's launch knobs (read from the environment by a development build of
+libqplace.so) on the benchmark workload and prints one line per setting."""
+import itertools
+import os
+import random
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from bench import make_partitions  # noqa: E402
+from quantum_simulator_amd import layered_gate_arrays  # noqa: E402
+from quantum_simulator_amd.engine import DeviceCircuit, DistanceTable, Engine, apsp  # noqa: E402
+from quantum_simulator_amd.multicore import graph_tables, multicore  # noqa: E402
+from quantum_simulator_amd.timeslices import CircuitIR  # noqa: E402
+
+
+def main():
+    dev = torch.device("cuda", 0)
+    Q, T, B = 1024, 1000, 4096
+    q0, q1, _ = layered_gate_arrays(Q, T, 0.5, seed=2025)
+    ir = CircuitIR.from_gate_tables(Q, q0, q1)
+    dc, eng = DeviceCircuit(ir, dev), Engine(dev)
+    A = make_partitions(torch, dev, B, ir.T, Q, dc.ldq, 256, 8, 0.95, seed=777)
+    out = torch.empty(B, dtype=torch.float64, device=dev)
+    random.seed(1234)
+    weights = (2.0, 2.0) if len(sys.argv) < 2 or sys.argv[1] == "integer" else (1.0, 3.0)
+    arch = multicore(16, 16, ncm_qubits=4, ncp_qubits=8, edge_weight_range=weights, network_type="mesh")
+    nodes, eu, ev, w = graph_tables(arch.network)
+    dt = DistanceTable(apsp(len(nodes), eu, ev, w), dev)
+    table = sys.argv[2] if len(sys.argv) > 2 else "packed"
+    knobs = {k: v.split(",") for k, v in (a.split("=") for a in sys.argv[3:])}
+    names = sorted(knobs)
+    ref = None
+    for combo in itertools.product(*[knobs[n] for n in names]):
+        for n, v in zip(names, combo):
+            os.environ[n] = v
+        for _ in range(3):
+            eng.cost_v3(dc, dt, A, out=out, table=table)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            eng.cost_v3(dc, dt, A, out=out, table=table)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        cs = float(out.sum().item())
+        ref = cs if ref is None else ref
+        print(dict(zip(names, combo)), f"{ms:.3f} ms  {B * T * Q / ms / 1e6 / 8000:.3f} of HBM peak",
+              "OK" if cs == ref or table != "packed" else f"MISMATCH {cs} {ref}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
