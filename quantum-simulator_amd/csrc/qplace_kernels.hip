@@ -311,11 +311,14 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_row(V3Args p) {
     }
     const int ldq = p.ldq;
     const uint32_t C = (uint32_t)p.C;
-    const uint32_t band_base = (uint32_t)p.band_lo << 8, band_span = (uint32_t)p.band_rows << 8;
-    // (from << 8 | to) -> slot of the band table; everything outside the band -> the zero entry
-    auto band_slot = [&](uint32_t code) -> uint32_t {
-        const uint32_t x = code - band_base;
-        return x < band_span ? x : band_span;
+    // Band mode: the band starts at a multiple of its (power of two) number of rows, so XOR-ing the
+    // source core with band_lo maps the band onto 0..band_rows-1 and everything else above it; the byte
+    // offset of (from ^ band_lo) << 8 | to is then clamped onto the zero entry that follows the band.
+    const uint32_t band_x4 = (uint32_t)p.band_lo * 0x01010101u;
+    const uint32_t band_slots = (uint32_t)p.band_rows << 8;  // <= 2^14: fits the 16-bit packed minimum
+    const uint32_t band_end = band_slots * (uint32_t)sizeof(E);
+    auto band_at = [&](uint32_t byte_off) -> Acc {
+        return *reinterpret_cast<const E*>(smem + min(byte_off, band_end));
     };
     uint8_t* strip = smem + tab_off + (size_t)wave * ldq;
     const bool lane_on = lane * 16 < ldq;
@@ -328,7 +331,7 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_row(V3Args p) {
     }
     auto pair_at = [&](uint32_t from, uint32_t to) -> Acc {
         if constexpr (TABMODE == kTabLds256) return tab[(from << 8) | to];
-        else if constexpr (TABMODE == kTabLdsBand) return tab[band_slot((from << 8) | to)];
+        else if constexpr (TABMODE == kTabLdsBand) return band_at(((((from ^ (uint32_t)p.band_lo) << 8) | to)) * (uint32_t)sizeof(E));
         else return tab[__umul24(from, C) + to];
     };
     auto four = [&](uint32_t pf, uint32_t cf) -> Acc {
@@ -337,10 +340,13 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_row(V3Args p) {
             const uint32_t hi = __builtin_amdgcn_perm(pf, cf, 0x07030602u);
             return (Acc)tab[lo & 0xFFFFu] + (Acc)tab[lo >> 16] + (Acc)tab[hi & 0xFFFFu] + (Acc)tab[hi >> 16];
         } else if constexpr (TABMODE == kTabLdsBand) {
-            const uint32_t lo = __builtin_amdgcn_perm(pf, cf, 0x05010400u);
-            const uint32_t hi = __builtin_amdgcn_perm(pf, cf, 0x07030602u);
-            return (Acc)tab[band_slot(lo & 0xFFFFu)] + (Acc)tab[band_slot(lo >> 16)] +
-                   (Acc)tab[band_slot(hi & 0xFFFFu)] + (Acc)tab[band_slot(hi >> 16)];
+            // two 16-bit slots per dword, both clamped onto the zero entry by one packed minimum
+            typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+            const uint32_t px = pf ^ band_x4;
+            const u16x2 cap = {(unsigned short)band_slots, (unsigned short)band_slots};
+            const u16x2 lo = __builtin_elementwise_min(__builtin_bit_cast(u16x2, __builtin_amdgcn_perm(px, cf, 0x05010400u)), cap);
+            const u16x2 hi = __builtin_elementwise_min(__builtin_bit_cast(u16x2, __builtin_amdgcn_perm(px, cf, 0x07030602u)), cap);
+            return ((Acc)tab[lo.x] + (Acc)tab[lo.y]) + ((Acc)tab[hi.x] + (Acc)tab[hi.y]);
         } else {
             Acc s = 0;
 #pragma unroll
@@ -783,8 +789,8 @@ int device_cus() {
 int rows_per_item_for(int32_t T, int32_t G, int64_t B, int cus) {
     if (G == 1) {
         // one row per step: long items amortise the pipeline fill at an item's start (the first rows are
-        // waited for with nothing else in flight); keep about 8 items per resident wave for balance
-        const int64_t want = (int64_t)T * B / ((int64_t)cus * kV3Waves * 8);
+        // waited for with nothing else in flight); keep about 4 items per resident wave for balance
+        const int64_t want = (int64_t)T * B / ((int64_t)cus * kV3Waves * 4);
         return (int)std::min<int64_t>(256, std::max<int64_t>(32, want));
     }
     // about 32 rows per item, a multiple of the group size, so the one extra row read per item is ~3%
@@ -854,7 +860,6 @@ extern "C" int qp_slice_cost_v3(const QpCircuit* circ, const QpDTable* dt, const
     }
     const int cus = device_cus();
     p.rows_per_item = rows_per_item_for(T, p.G, B, cus);
-    if (getenv("QP_TUNE_ROWS")) p.rows_per_item = atoi(getenv("QP_TUNE_ROWS"));
     const int32_t nchunks = (T + p.rows_per_item - 1) / p.rows_per_item;
     p.nitems = (int64_t)nchunks * B;
     if (!workspace || workspace_bytes < (size_t)p.nitems * sizeof(double))
@@ -893,11 +898,8 @@ extern "C" int qp_slice_cost_v3(const QpCircuit* circ, const QpDTable* dt, const
             p.gwy = g.wy;
             p.gyi = p.gym << p.gxb;
             const bool wrap = g.wrap_x || g.wrap_y;
-            const int ahead = getenv("QP_TUNE_AHEAD") ? atoi(getenv("QP_TUNE_AHEAD")) : 3;
             if (!rowpath) kern = k_cost_v3<QP_DT_U16, kTabGrid>;
-            else if (wrap) kern = k_cost_v3_grid_row<true, 3>;
-            else kern = ahead == 2 ? k_cost_v3_grid_row<false, 2> : ahead == 4 ? k_cost_v3_grid_row<false, 4>
-                      : ahead == 6 ? k_cost_v3_grid_row<false, 6> : k_cost_v3_grid_row<false, 3>;
+            else kern = wrap ? k_cost_v3_grid_row<true, kV3Ahead> : k_cost_v3_grid_row<false, kV3Ahead>;
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)strips));
             int per_cu = 1;
             HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), kV3Threads, strips));
@@ -910,7 +912,8 @@ extern "C" int qp_slice_cost_v3(const QpCircuit* circ, const QpDTable* dt, const
         }
         if (rowpath && mode == kTabGlobal && dt->kind == QP_DT_F64) {
             // fp64 table too big for LDS: one pass per band of source cores, each with its band in LDS
-            const int band_rows = (int)std::min<size_t>(dt->C, ((size_t)kLdsBytes - strips - 16) / (256 * esz));
+            int band_rows = 1;  // largest power of two whose band fits beside the strips
+            while ((size_t)band_rows * 2 * 256 * esz + 16 + strips <= (size_t)kLdsBytes) band_rows *= 2;
             const int passes = (dt->C + band_rows - 1) / band_rows;
             if (workspace_bytes < (size_t)passes * p.nitems * sizeof(double))
                 return qp::fail(QP_ENOSPC, "qp_slice_cost_v3: workspace needs %zu bytes", (size_t)passes * p.nitems * sizeof(double));

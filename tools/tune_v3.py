@@ -1,5 +1,6 @@
-"""Sweeps the dense cost kernel's launch knobs (read from the environment by a development build of
-libqplace.so) on the benchmark workload and prints one line per setting."""
+"""Times the dense cost kernel on the benchmark workload: tune_v3.py [integer|uniform] [packed|table|f64].
+Extra NAME=v1,v2 arguments are exported as environment variables and swept (for development builds of
+libqplace.so that read launch knobs from the environment; the committed library reads none)."""
 import itertools
 import os
 import random
