@@ -143,8 +143,8 @@ def bench_cost_matrix(torch, dev, dc, ir, D, B, steps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--weights", choices=["uniform", "integer"], default="integer",
                     help="edge weights of the headline number: integer (2,2) -> exact uint16 table in LDS; "
                          "uniform(1,3) -> fp64 table; the other one is run too and reported under other_variants")
