@@ -717,12 +717,14 @@ struct CmArgs {
 __device__ inline double pymax(double a, double b) { return b > a ? b : a; }  // Python's max(a, b)
 
 // One workgroup = one instance x kCmOps consecutive ops; thread j owns available-core column j.
-// Everything that depends on the op only (its qubits' cores, the cores of the look-ahead partners) is
-// the same for all threads, so the compiler keeps it in scalar registers; per thread there are two
-// distance loads, six compares and one coalesced 8-byte store per entry.
+// What depends on the op only (the cores of its two qubits and of its up to six look-ahead partners)
+// hangs on a chain of dependent loads (op -> gate -> qubit -> core).  kCmOps * 8 threads walk one chain
+// each, side by side, and leave the eight cores in LDS; after that every entry costs two coalesced
+// distance loads, two broadcast LDS reads, the reference's arithmetic and one coalesced 8-byte store.
 constexpr int kCmOps = 16;
 
 __global__ __launch_bounds__(256) void k_cost_matrix(CmArgs p) {
+    __shared__ __align__(16) int32_t opinfo[kCmOps][8];  // [0..5] partner cores (-1 = none), [6] a1, [7] a2
     const int64_t b = blockIdx.y;
     const int n_ops = p.n_ops[b], n_av = p.n_avail[b];
     const int i0 = blockIdx.x * kCmOps;
@@ -730,12 +732,26 @@ __global__ __launch_bounds__(256) void k_cost_matrix(CmArgs p) {
     const int i1 = min(n_ops, i0 + kCmOps);
     const uint8_t* a = p.a + (size_t)b * p.ldq;
     const int C = p.C;
-    for (int j = threadIdx.x; j < n_av; j += blockDim.x) {
-        const uint32_t c = p.avail[(size_t)b * C + j];
-        for (int i = i0; i < i1; ++i) {
+    if (threadIdx.x < kCmOps * 8) {
+        const int i = i0 + (threadIdx.x >> 3), k = threadIdx.x & 7;
+        int32_t v = -1;
+        if (i < i1) {
             const int eid = p.ops[(size_t)b * p.max_ops + i];
-            const QpEdge ed = p.edges[eid];
-            const uint32_t a1 = a[ed.u], a2 = a[ed.v];
+            int q;
+            if (k < 6) q = p.kind == QP_CM_GTRHQA ? -1 : p.lookahead[(size_t)eid * 6 + k];
+            else q = k == 6 ? p.edges[eid].u : p.edges[eid].v;
+            if (q >= 0) v = a[q];
+        }
+        opinfo[threadIdx.x >> 3][k] = v;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < n_av; j += blockDim.x) {
+        const int32_t c = p.avail[(size_t)b * C + j];
+        double* outp = p.out + ((size_t)b * p.max_ops + i0) * C + j;
+        for (int i = 0; i < i1 - i0; ++i) {
+            const int4 pc03 = *reinterpret_cast<const int4*>(&opinfo[i][0]);
+            const int4 pc47 = *reinterpret_cast<const int4*>(&opinfo[i][4]);
+            const int32_t a1 = pc47.z, a2 = pc47.w;
             const double d1 = p.D[a1 * C + c], d2 = p.D[a2 * C + c];
             double r;
             if (p.kind == QP_CM_GTRHQA) {
@@ -745,14 +761,13 @@ __global__ __launch_bounds__(256) void k_cost_matrix(CmArgs p) {
                 if (a2 != 0 && a2 != c) cost += d2;
                 r = cost;
             } else {
+                const int32_t pc[6] = {pc03.x, pc03.y, pc03.z, pc03.w, pc47.x, pc47.y};
                 double att = 0.0;
-                const int16_t* la = p.lookahead + (size_t)eid * 6;
 #pragma unroll
                 for (int k = 0; k < 6; ++k) {
-                    const int o = la[k];
-                    if (o >= 0) {
+                    if (pc[k] >= 0) {
                         const double w = k < 2 ? 0.5 : (k < 4 ? 0.25 : 0.125);
-                        att += (a[o] == c) ? w * 0.9 : w * 0.3;
+                        att += (pc[k] == c) ? w * 0.9 : w * 0.3;
                     }
                 }
                 if (p.kind == QP_CM_HQA) {
@@ -770,7 +785,7 @@ __global__ __launch_bounds__(256) void k_cost_matrix(CmArgs p) {
                     r = pymax(0.1, here - attraction);
                 }
             }
-            p.out[((size_t)b * p.max_ops + i) * C + j] = r;
+            outp[(size_t)i * C] = r;
         }
     }
 }
