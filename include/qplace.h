@@ -207,6 +207,20 @@ int qp_cost_matrix(int32_t kind, const QpCircuit* circ, const QpDTable* dt, int6
                    int32_t max_ops, const uint8_t* avail, const int32_t* n_avail, double* cost_out,
                    void* stream);
 
+/* ---------------------------------------------------------------- device: GTRHQA placement */
+
+/* B independent GTRHQA placements of one circuit, every timeslice on the device (one workgroup walks
+ * one instance; no host round trip per slice).  Replaces gtrhqa_placer.place_per_timeslice,
+ * GTRHQA_placer.py:62-265: slice t starts from row t-1 (row 0 for t = 0) and its result is row t+1;
+ * rows = the slice's counted gates whose qubits sit on different cores (slice order), columns = cores
+ * holding at most cap-2 qubits when the slice starts (ascending); entries as QP_CM_GTRHQA; assignment by
+ * the bidding rounds of :128-220 and the leftover pass of :222-254.
+ * initial: dev uint8 [B][ldq] core index per qubit (< C; row 0 of every instance).  out: dev uint8
+ * [B][T+1][ldq]; row 0 is a copy of initial (pad columns included), the rest follow.
+ * dt must be QP_DT_F64.  The caller checks what the reference checks before it starts (capacity). */
+int qp_gtrhqa_place(const QpCircuit* circ, const QpDTable* dt, const uint8_t* initial, int64_t B, int32_t ldq,
+                    int32_t cap, uint8_t* out, void* stream);
+
 /* ---------------------------------------------------------------- device: QUBO placer */
 
 /* The QUBO placer's objective (Qubo_placer.py:84-133) over binary variables x[t,j,i] (active qubit i

@@ -223,6 +223,22 @@ class Engine:
         return out
 
 
+    def gtrhqa_place(self, dc: DeviceCircuit, dt: DistanceTable, initial, cap: int, out=None):
+        """B GTRHQA placements on the device.  initial: uint8 [B, ldq] device tensor (row 0 of every
+        instance, core indices < C); returns uint8 [B, T+1, ldq]."""
+        torch = _torch()
+        if initial.dtype != torch.uint8 or initial.dim() != 2 or not initial.is_contiguous() or initial.device != self.device:
+            raise ValueError("initial must be a contiguous uint8 [B, ldq] tensor on the engine's device")
+        B, ldq = initial.shape
+        if ldq % 16 or ldq < dc.ir.Q:
+            raise ValueError("row pitch must be a multiple of 16 and >= Q")
+        if out is None:
+            out = torch.empty((B, dc.ir.T + 1, ldq), dtype=torch.uint8, device=self.device)
+        check(lib().qp_gtrhqa_place(C.byref(dc.c), C.byref(dt.f64), initial.data_ptr(), B, ldq, int(cap),
+                                    out.data_ptr(), _stream_ptr(self.device)))
+        return out
+
+
 def rows_to_array(rows, Q, ldq=None, absent=QP_ABSENT) -> np.ndarray:
     """List of rows (core index or None per qubit) -> uint8 [Tp, ldq]."""
     ldq = ldq if ldq is not None else (Q + 15) // 16 * 16

@@ -388,128 +388,40 @@ class gtrhqa_placer(_HqaFamily):
 
     def place_rows(self, ctx: _Context, cap: int):
         """GTRHQA_placer.py:62-265.  Returns T+1 rows: slice t starts from row t-1 (row 0 for t = 0)
-        and its result is appended as row t+1, exactly as the reference's loop does."""
+        and its result is appended as row t+1, exactly as the reference's loop does.  Every slice runs
+        on the device (qp_gtrhqa_place)."""
+        Q = ctx.ir.Q
+        out = self._place_on_device(ctx, cap, self._initial(Q, cap)[None])
+        return [out[0, t] for t in range(out.shape[1])]
+
+    def _place_on_device(self, ctx: _Context, cap: int, initial: np.ndarray, as_tensor=False):
+        import torch
         ir, C = ctx.ir, ctx.arch.C
-        Q, T = ir.Q, ir.T
+        Q = ir.Q
         self._check_capacity(Q, C, cap)
-        init = self._initial(Q, cap)
-        rows = [init]
-        for t in range(T):
-            prev = rows[t - 1] if t > 0 else init
-            a = prev.copy()
-            ops = [op for op in ir.slice_ops(t) if prev[op[1]] != prev[op[2]]]
-            if ops:
-                occ = np.bincount(a, minlength=C)
-                avail = np.flatnonzero(occ <= cap - 2)
-                if avail.size:
-                    M = ctx.cost_matrix(QP_CM_GTRHQA, t, a, [e for e, _, _ in ops], avail)
-                    for k, j in greedy_rounds(M):
-                        _, u, v = ops[k]
-                        a[u] = avail[j]
-                        a[v] = avail[j]
-            rows.append(a)
-        return rows
+        if cap < 2:
+            raise ValueError("GTRHQA needs cores that hold at least two qubits")
+        initial = np.ascontiguousarray(initial, np.uint8)
+        if initial.ndim != 2 or initial.shape[1] != Q:
+            raise ValueError("initial must be [B, Q]")
+        if initial.size and int(initial.max()) >= C:
+            raise ValueError("initial holds a core index outside the architecture")
+        ldq = ctx.dc.ldq
+        pad = np.zeros((initial.shape[0], ldq), np.uint8)
+        pad[:, :Q] = initial
+        rows = ctx.eng.gtrhqa_place(ctx.dc, ctx.arch.table, torch.from_numpy(pad).to(ctx.device), cap)
+        if as_tensor:
+            return rows
+        return rows.cpu().numpy()[:, :, :Q]
 
-
-def _gtrhqa_place_batch(self, circuit, multicore_arch, initial=None, B=None, threads=8):
-    """GTRHQA in lock-step: one cost-matrix launch per slice for all instances, then the greedy
-    rounds per instance on the host.  Returns uint8 [B, T+1, Q] (the reference's T+1 rows)."""
-    import torch
-    ctx = self._context(circuit, multicore_arch)
-    cap = multicore_arch.qpu_qubit_num
-    ir, C = ctx.ir, ctx.arch.C
-    Q, T = ir.Q, ir.T
-    self._check_capacity(Q, C, cap)
-    if initial is None:
-        initial = np.tile(self._initial(Q, cap), (B or 1, 1))
-    initial = np.ascontiguousarray(initial, np.uint8)
-    B = initial.shape[0]
-    out = np.empty((B, T + 1, Q), np.uint8)
-    out[:, 0] = initial
-    dev = ctx.device
-    sep = ir.slice_edge_ptr
-    base_off = (np.arange(B, dtype=np.int64) * C)[:, None]
-    for t in range(T):
-        a = (out[:, t - 1] if t > 0 else initial).copy()
-        e0, e1 = int(sep[t]), int(sep[t + 1])
-        if e1 > e0:
-            eu, ev = ir.edge_u[e0:e1].astype(np.int64), ir.edge_v[e0:e1].astype(np.int64)
-            rem = a[:, eu] != a[:, ev]
-            occ = np.bincount((a.astype(np.int64) + base_off).ravel(), minlength=B * C).reshape(B, C)
-            room = occ <= cap - 2
-            go = np.flatnonzero(rem.any(1) & room.any(1))
-            if go.size:
-                n_ops = rem[go].sum(1).astype(np.int32)
-                n_av = room[go].sum(1).astype(np.int32)
-                ops = np.zeros((go.size, int(n_ops.max())), np.int32)
-                avail = np.zeros((go.size, C), np.uint8)
-                op_lists, av_lists = [], []
-                for k, b in enumerate(go):
-                    idx, av = np.flatnonzero(rem[b]), np.flatnonzero(room[b])
-                    ops[k, :idx.size] = e0 + idx
-                    avail[k, :av.size] = av
-                    op_lists.append(idx)
-                    av_lists.append(av)
-                ab = np.zeros((go.size, ctx.dc.ldq), np.uint8)
-                ab[:, :Q] = a[go]
-                M = ctx.eng.cost_matrix(
-                    QP_CM_GTRHQA, ctx.dc, ctx.arch.table, torch.full((go.size,), t, dtype=torch.int32, device=dev),
-                    torch.from_numpy(ab).to(dev), torch.from_numpy(ops).to(dev), torch.from_numpy(n_ops).to(dev),
-                    torch.from_numpy(avail).to(dev), torch.from_numpy(n_av).to(dev)).cpu().numpy()
-                for k, b in enumerate(go):
-                    for i, j in greedy_rounds(M[k, :n_ops[k], :n_av[k]]):
-                        e = op_lists[k][i]
-                        a[b, eu[e]] = av_lists[k][j]
-                        a[b, ev[e]] = av_lists[k][j]
-        out[:, t + 1] = a
-    return out
-
-
-gtrhqa_placer.place_batch = _gtrhqa_place_batch
-
-
-def greedy_rounds(M: np.ndarray):
-    """The assignment rule of GTRHQA_placer.py:128-254 on one cost matrix: in each round every
-    unassigned op bids for its cheapest free core (first minimum); a core takes the cheapest bidder
-    (first minimum, ops in index order); at most min(ops, cores) + 2 rounds, then leftovers take their
-    cheapest remaining core in op order.  Yields (op, core column) pairs in application order."""
-    nops, nav = M.shape
-    finite = np.isfinite(M)
-    Mm = np.where(finite, M, 1e12)
-    op_left = np.ones(nops, bool)
-    core_free = np.ones(nav, bool)
-    out = []
-    rounds = 0
-    while op_left.any() and core_free.any() and rounds < min(nav, nops) + 2:
-        rounds += 1
-        cols = np.flatnonzero(core_free)
-        rws = np.flatnonzero(op_left)
-        if not finite[np.ix_(rws, cols)].any():
-            break
-        sub = Mm[np.ix_(rws, cols)]
-        rel = np.argmin(sub, axis=1)
-        bid = sub[np.arange(len(rws)), rel]
-        target = cols[rel]
-        for core in np.unique(target):
-            who = np.flatnonzero(target == core)
-            k = int(rws[who[int(np.argmin(bid[who]))]])
-            if not finite[k, core]:
-                continue
-            op_left[k] = False
-            core_free[core] = False
-            out.append((k, int(core)))
-    left = [int(j) for j in np.flatnonzero(core_free)]
-    for k in np.flatnonzero(op_left).tolist():
-        if not left:
-            break
-        vals = M[k, left]
-        ok = np.isfinite(vals)
-        if not ok.any():
-            continue
-        j = left[int(np.argmin(np.where(ok, vals, 1e12)))]
-        out.append((k, j))
-        left.remove(j)
-    return out
+    def place_batch(self, circuit, multicore_arch, initial=None, B=None, threads=8, as_tensor=False):
+        """B placements in one launch.  Returns uint8 [B, T+1, Q] (the reference's T+1 rows), or with
+        as_tensor the device tensor [B, T+1, ldq] that Engine.cost_v3 takes as it is."""
+        ctx = self._context(circuit, multicore_arch)
+        cap = multicore_arch.qpu_qubit_num
+        if initial is None:
+            initial = np.tile(self._initial(ctx.ir.Q, cap), (B or 1, 1))
+        return self._place_on_device(ctx, cap, initial, as_tensor=as_tensor)
 
 
 # ------------------------------------------------------------------------------------------------

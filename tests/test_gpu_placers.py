@@ -144,3 +144,49 @@ def test_place_batch_lockstep(name, pname):
             want = O.place_hqa_family(gc.slices, gc.gate_q, gc.gate_mr, gc.Q, gc.C, gc.cap, D, pname.lower(),
                                       init=inits[b].tolist())
         assert (got[b] == np.array(want, np.uint8)).all(), (pname, b)
+
+
+GTR_SHAPES = [  # Q, T, C, cap, instances, disconnected graph
+    (40, 30, 8, 6, 4, False), (200, 20, 32, 8, 5, False), (33, 12, 5, 8, 3, False), (64, 15, 16, 4, 4, False),
+    (48, 10, 8, 6, 3, True), (300, 8, 64, 6, 3, True), (1024, 5, 256, 8, 3, False), (16, 9, 8, 2, 2, False),
+]
+
+
+@pytest.mark.parametrize("Q,T,C,cap,B,disconnected", GTR_SHAPES)
+def test_gtrhqa_device_placement_matches_oracle(Q, T, C, cap, B, disconnected):
+    """qp_gtrhqa_place (every slice on the device) against the sequential restatement, row for row,
+    from shuffled starting assignments; includes graphs with unreachable cores (infinite distances)
+    and capacities that leave few or no cores with room."""
+    import torch
+    from oracle import placer_oracle as O
+    from quantum_simulator_amd import engine, layered_gate_arrays
+    from quantum_simulator_amd.timeslices import CircuitIR
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(Q * 31 + T)
+    q0, q1, _ = layered_gate_arrays(Q, T, 0.6, seed=Q + T)
+    keep = rng.random(len(q0)) > 0.25
+    ir = CircuitIR.from_gate_tables(Q, q0[keep], q1[keep])
+    if disconnected:  # two rings that do not touch
+        h = C // 2
+        eu = list(range(C))
+        ev = [(i + 1) % h for i in range(h)] + [h + (i + 1) % (C - h) for i in range(C - h)]
+    else:  # ring + chords
+        eu = list(range(C)) + [int(x) for x in rng.integers(0, C, size=C // 2)]
+        ev = [(i + 1) % C for i in range(C)] + [int(x) for x in rng.integers(0, C, size=C // 2)]
+    ok = [k for k in range(len(eu)) if eu[k] != ev[k]]
+    eu, ev = [eu[k] for k in ok], [ev[k] for k in ok]
+    w = rng.uniform(1, 3, size=len(eu))
+    D = engine.apsp(C, eu, ev, w)
+    assert np.isinf(D).any() == disconnected
+    dc, dt, eng = engine.DeviceCircuit(ir, dev), engine.DistanceTable(D, dev), engine.Engine(dev)
+    slots = np.repeat(np.arange(C), cap)
+    inits = np.stack([rng.permutation(slots)[:Q] for _ in range(B)]).astype(np.uint8)
+    inits[0] = np.arange(Q) // cap  # the reference's own starting assignment
+    pad = np.zeros((B, dc.ldq), np.uint8)
+    pad[:, :Q] = inits
+    got = eng.gtrhqa_place(dc, dt, torch.from_numpy(pad).to(dev), cap).cpu().numpy()
+    assert got.shape == (B, ir.T + 1, dc.ldq)
+    Dl = D.tolist()
+    for b in range(B):
+        want = np.array(O.place_gtrhqa(ir.slices, ir.gate_q, ir.gate_mr, Q, C, cap, Dl, init=inits[b].tolist()), np.uint8)
+        assert (got[b, :, :Q] == want).all(), (b, np.argwhere(got[b, :, :Q] != want)[:5])
