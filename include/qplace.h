@@ -63,6 +63,8 @@ typedef struct QpCircuit {
     int32_t T;  /* timeslices */
     int32_t nE; /* counted two-qubit gates */
     int32_t nV; /* visits */
+    int32_t max_slice_edges; /* most counted gates in one slice; 0 = not given (Q/2 is assumed) */
+    int32_t reserved_;
     const int32_t* slice_edge_ptr;  /* [T+1] CSR over edges */
     const QpEdge* edges;            /* [nE] */
     const int16_t* lookahead;       /* [nE*6] other-qubit of the <=2 two-qubit commands that touch
@@ -217,9 +219,11 @@ int qp_cost_matrix(int32_t kind, const QpCircuit* circ, const QpDTable* dt, int6
  * the bidding rounds of :128-220 and the leftover pass of :222-254.
  * initial: dev uint8 [B][ldq] core index per qubit (< C; row 0 of every instance).  out: dev uint8
  * [B][T+1][ldq]; row 0 is a copy of initial (pad columns included), the rest follow.
- * dt must be QP_DT_F64.  The caller checks what the reference checks before it starts (capacity). */
+ * dt must be QP_DT_F64.  The caller checks what the reference checks before it starts (capacity).
+ * workspace: dev, qp_gtrhqa_workspace(C) bytes, 8-byte aligned (a prepared copy of the table). */
+size_t qp_gtrhqa_workspace(int32_t C);
 int qp_gtrhqa_place(const QpCircuit* circ, const QpDTable* dt, const uint8_t* initial, int64_t B, int32_t ldq,
-                    int32_t cap, uint8_t* out, void* stream);
+                    int32_t cap, uint8_t* out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------- device: QUBO placer */
 

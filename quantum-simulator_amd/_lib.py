@@ -19,6 +19,7 @@ QP_SCHED_CHUNK, QP_SCHED_TAIL = 64, 512
 
 class QpCircuit(C.Structure):
     _fields_ = [("Q", C.c_int32), ("T", C.c_int32), ("nE", C.c_int32), ("nV", C.c_int32),
+                ("max_slice_edges", C.c_int32), ("reserved_", C.c_int32),
                 ("slice_edge_ptr", C.c_void_p), ("edges", C.c_void_p), ("lookahead", C.c_void_p),
                 ("slice_visit_ptr", C.c_void_p), ("visits", C.c_void_p), ("edges_sched", C.c_void_p), ("sched_ptr", C.c_void_p)]
 
@@ -80,8 +81,9 @@ EXPORTS = {
     "qp_cost_matrix": (C.c_int, [C.c_int32, C.POINTER(QpCircuit), C.POINTER(QpDTable), C.c_int64, C.c_void_p,
                                  C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p]),
+    "qp_gtrhqa_workspace": (C.c_size_t, [C.c_int32]),
     "qp_gtrhqa_place": (C.c_int, [C.POINTER(QpCircuit), C.POINTER(QpDTable), C.c_void_p, C.c_int64, C.c_int32,
-                                  C.c_int32, C.c_void_p, C.c_void_p]),
+                                  C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "qp_qubo_fields_i32": (C.c_int, [C.POINTER(QpQuboDense), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "qp_qubo_energy_i32": (C.c_int, [C.POINTER(QpQuboDense), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "qp_qubo_anneal": (C.c_int, [C.POINTER(QpQuboStruct), C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_uint64,

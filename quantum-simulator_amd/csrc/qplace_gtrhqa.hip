@@ -18,7 +18,7 @@
 
 namespace {
 
-constexpr int kThreads = 256;
+constexpr int kThreads = 1024;  // 16 waves: a round's argmins (one wave each) run side by side
 constexpr int kWave = 64;
 constexpr int kWaves = kThreads / kWave;
 constexpr double kBig = 1e12;  // what a non-finite entry counts as in an argmin (GTRHQA_placer.py:139)
@@ -26,7 +26,8 @@ constexpr double kBig = 1e12;  // what a non-finite entry counts as in an argmin
 struct GpArgs {
     const int32_t* sep;
     const QpEdge* edges;
-    const double* D;
+    const double* D;            // prepared copy (row 0 and diagonal zero)
+    const int32_t* all_finite;  // 1 when every distance is finite
     const uint8_t* initial;
     uint8_t* out;
     int64_t B;
@@ -41,18 +42,58 @@ struct OpFlags {
 
 __device__ inline unsigned long long dbits(double x) { return (unsigned long long)__double_as_longlong(x); }
 
+// Lexicographic minimum of (key, idx) over the wave with DPP moves (no LDS traffic); every lane gets it.
+template <int CTRL, int ROW_MASK>
+__device__ inline void lexmin_step(unsigned long long& key, uint32_t& idx) {
+    const uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
+    const uint32_t olo = (uint32_t)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, ROW_MASK, 0xF, false);
+    const uint32_t ohi = (uint32_t)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, ROW_MASK, 0xF, false);
+    const uint32_t oidx = (uint32_t)__builtin_amdgcn_update_dpp((int)idx, (int)idx, CTRL, ROW_MASK, 0xF, false);
+    const unsigned long long okey = ((unsigned long long)ohi << 32) | olo;
+    if (okey < key || (okey == key && oidx < idx)) {
+        key = okey;
+        idx = oidx;
+    }
+}
+__device__ inline void lexmin_wave(unsigned long long& key, uint32_t& idx) {
+    lexmin_step<0xB1, 0xF>(key, idx);   // quad_perm [1,0,3,2]
+    lexmin_step<0x4E, 0xF>(key, idx);   // quad_perm [2,3,0,1]
+    lexmin_step<0x141, 0xF>(key, idx);  // row_half_mirror
+    lexmin_step<0x140, 0xF>(key, idx);  // row_mirror: every lane of a 16-lane row holds the row's minimum
+    lexmin_step<0x142, 0xA>(key, idx);  // row_bcast:15 into rows 1 and 3
+    lexmin_step<0x143, 0xC>(key, idx);  // row_bcast:31 into rows 2 and 3: lane 63 holds the wave's minimum
+    const uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)key, 63);
+    const uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), 63);
+    key = ((unsigned long long)hi << 32) | lo;
+    idx = (uint32_t)__builtin_amdgcn_readlane((int)idx, 63);
+}
+
 // GTRHQA_placer.py:99-112: sum over the op's two qubits of D[core of the qubit][c], skipping a qubit
-// that is on core c already or on core 0 (label 0 is falsy in the reference's test)
-__device__ inline double entry(const double* D, int C, uint32_t a1, uint32_t a2, uint32_t c) {
-    double cost = 0.0;
-    if (a1 != 0 && a1 != c) cost += D[a1 * C + c];
-    if (a2 != 0 && a2 != c) cost += D[a2 * C + c];
-    return cost;
+// that is on core c already or on core 0 (label 0 is falsy in the reference's test).  The skips are
+// folded into a copy of the table whose row 0 and diagonal are zero: 0.0 + x + 0.0 == x exactly, so the
+// sum has the bits of the reference's conditional additions.
+__device__ inline double entry(const double* Dz, int C, uint32_t a1, uint32_t a2, uint32_t c) {
+    return Dz[a1 * C + c] + Dz[a2 * C + c];
+}
+
+// Dz = D with row 0 and the diagonal zeroed; flag = 1 when every entry of D is finite.
+__global__ void k_gtrhqa_prepare(const double* D, int C, double* Dz, int32_t* all_finite) {
+    __shared__ int bad;
+    if (threadIdx.x == 0) bad = 0;
+    __syncthreads();
+    for (int k = threadIdx.x; k < C * C; k += blockDim.x) {
+        const int r = k / C, c = k - r * C;
+        const double v = D[k];
+        if (!isfinite(v)) bad = 1;
+        Dz[k] = (r == 0 || r == c) ? 0.0 : v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *all_finite = bad ? 0 : 1;
 }
 
 __global__ __launch_bounds__(kThreads) void k_gtrhqa_place(GpArgs p) {
     extern __shared__ __align__(16) uint8_t smem[];
-    __shared__ int s_nops, s_nav, s_nleft, s_nfree, s_flag, s_dfinite, s_wave_cnt[kWaves], s_base;
+    __shared__ int s_nops, s_nav, s_nleft, s_nfree, s_flag, s_wave_cnt[kWaves], s_base;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     const int C = p.C, Q = p.Q, ldq = p.ldq;
     uint8_t* rows = smem + p.off_rows;                                 // [2][ldq]
@@ -67,16 +108,8 @@ __global__ __launch_bounds__(kThreads) void k_gtrhqa_place(GpArgs p) {
     uint8_t* avail = smem + p.off_cores;                               // [C] core id of column j
     uint8_t* cfree = avail + C;                                        // [C] by column
 
-    // are all distances finite?  (then every entry is, and the "nothing finite left" test never fires)
-    if (tid == 0) s_dfinite = 1;
-    __syncthreads();
-    {
-        bool ok = true;
-        for (int k = tid; k < C * C; k += kThreads) ok = ok && isfinite(p.D[k]);
-        if (!ok) s_dfinite = 0;
-    }
-    __syncthreads();
-    const bool dfinite = s_dfinite != 0;
+    // all distances finite: then every entry is, and the "nothing finite left" test never fires
+    const bool dfinite = *p.all_finite != 0;
 
     for (int64_t b = blockIdx.x; b < p.B; b += gridDim.x) {
         uint8_t* outb = p.out + (size_t)b * (p.T + 1) * ldq;
@@ -159,6 +192,10 @@ __global__ __launch_bounds__(kThreads) void k_gtrhqa_place(GpArgs p) {
             }
             const int nops = s_nops, nav = s_nav;
             if (nops > 0 && nav > 0) {
+                // this lane's columns lane, lane + 64, ...: element offset of the core inside a table row
+                uint32_t coff[4];
+#pragma unroll
+                for (int jb = 0; jb < 4; ++jb) coff[jb] = avail[min(jb * kWave + lane, nav - 1)];
                 if (tid == 0) {
                     s_nleft = nops;
                     s_nfree = nav;
@@ -185,39 +222,41 @@ __global__ __launch_bounds__(kThreads) void k_gtrhqa_place(GpArgs p) {
                         if (!go) break;
                     }
                     // every open op without a standing bid looks for its cheapest free core (first minimum)
+                    uint32_t fmask = 0;  // bit jb: this lane's column jb * 64 + lane exists and is free
+#pragma unroll
+                    for (int jb = 0; jb < 4; ++jb) {
+                        const int j = jb * kWave + lane;
+                        if (j < nav && cfree[j]) fmask |= 1u << jb;
+                    }
                     for (int k = wave; k < nops; k += kWaves) {
                         const OpFlags f = flags[k];
                         if (!f.left || !f.need) continue;
-                        const uint32_t a1 = a12[k] & 0xFF, a2 = a12[k] >> 8;
-                        double bv = 0.0;
-                        int bj = 0x7FFFFFFF;
-                        bool bfin = false;
-                        for (int j = lane; j < nav; j += kWave) {
-                            if (!cfree[j]) continue;
-                            const double val = entry(p.D, C, a1, a2, avail[j]);
-                            const bool fin = isfinite(val);
-                            const double vm = fin ? val : kBig;
-                            if (bj == 0x7FFFFFFF || vm < bv) {
-                                bv = vm;
-                                bj = j;
-                                bfin = fin;
-                            }
-                        }
+                        const uint32_t a1 = __builtin_amdgcn_readfirstlane(a12[k] & 0xFF);
+                        const uint32_t a2 = __builtin_amdgcn_readfirstlane(a12[k] >> 8);
+                        const double* r1 = p.D + (size_t)a1 * C;  // wave-uniform row bases
+                        const double* r2 = p.D + (size_t)a2 * C;
+                        // key = bits of the entry (non-negative doubles order like their bits), idx = column
+                        // with "finite" in bit 16; a lane looks at its columns in ascending order, so "<"
+                        // keeps its first minimum and the wave minimum breaks ties by column
+                        unsigned long long key = ~0ull;
+                        uint32_t idx = 0x7FFFFFFFu;
 #pragma unroll
-                        for (int off = 32; off > 0; off >>= 1) {
-                            const double ov = __shfl_xor(bv, off, kWave);
-                            const int oj = __shfl_xor(bj, off, kWave);
-                            const int ofin = __shfl_xor((int)bfin, off, kWave);
-                            if (oj != 0x7FFFFFFF && (bj == 0x7FFFFFFF || ov < bv || (ov == bv && oj < bj))) {
-                                bv = ov;
-                                bj = oj;
-                                bfin = ofin != 0;
+                        for (int jb = 0; jb < 4; ++jb) {
+                            if (jb * kWave < nav) {  // uniform
+                                const double val = r1[coff[jb]] + r2[coff[jb]];
+                                const bool fin = dfinite || isfinite(val);
+                                const unsigned long long kk = dbits(fin ? val : kBig);
+                                if (((fmask >> jb) & 1u) && kk < key) {
+                                    key = kk;
+                                    idx = (uint32_t)(jb * kWave + lane) | (fin ? 0x10000u : 0u);
+                                }
                             }
                         }
+                        lexmin_wave(key, idx);
                         if (lane == 0) {
-                            bid[k] = bv;
-                            target[k] = bj;
-                            flags[k] = OpFlags{1, 0, (uint8_t)bfin, 0};
+                            bid[k] = __longlong_as_double((long long)key);
+                            target[k] = (int)(idx & 0xFFFFu);
+                            flags[k] = OpFlags{1, 0, (uint8_t)((idx >> 16) & 1u), 0};
                         }
                     }
                     for (int j = tid; j < nav; j += kThreads) {
@@ -301,8 +340,12 @@ __global__ __launch_bounds__(kThreads) void k_gtrhqa_place(GpArgs p) {
 
 }  // namespace
 
+extern "C" size_t qp_gtrhqa_workspace(int32_t C) {
+    return C > 0 ? (size_t)C * C * sizeof(double) + 16 : 16;
+}
+
 extern "C" int qp_gtrhqa_place(const QpCircuit* circ, const QpDTable* dt, const uint8_t* initial, int64_t B, int32_t ldq,
-                               int32_t cap, uint8_t* out, void* stream_) {
+                               int32_t cap, uint8_t* out, void* workspace, size_t workspace_bytes, void* stream_) {
     if (!circ || !dt || !initial || !out) return qp::fail(QP_EINVAL, "qp_gtrhqa_place: null argument");
     if (B <= 0) return qp::fail(QP_EINVAL, "qp_gtrhqa_place: B must be positive");
     if (circ->Q <= 0 || circ->Q > 65535 || circ->T < 0) return qp::fail(QP_EINVAL, "qp_gtrhqa_place: bad circuit sizes");
@@ -312,15 +355,22 @@ extern "C" int qp_gtrhqa_place(const QpCircuit* circ, const QpDTable* dt, const 
     if (cap < 2) return qp::fail(QP_EINVAL, "qp_gtrhqa_place: capacity must be at least 2");
     if (circ->T > 0 && (!circ->slice_edge_ptr || (circ->nE > 0 && !circ->edges)))
         return qp::fail(QP_EINVAL, "qp_gtrhqa_place: circuit edge tables missing");
+    if (!workspace || workspace_bytes < qp_gtrhqa_workspace(dt->C) || (reinterpret_cast<uintptr_t>(workspace) & 7))
+        return qp::fail(QP_ENOSPC, "qp_gtrhqa_place: workspace needs %zu bytes, 8-byte aligned", qp_gtrhqa_workspace(dt->C));
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    double* Dz = static_cast<double*>(workspace);
+    int32_t* all_finite = reinterpret_cast<int32_t*>(Dz + (size_t)dt->C * dt->C);
+    k_gtrhqa_prepare<<<1, 1024, 0, stream>>>(static_cast<const double*>(dt->table), dt->C, Dz, all_finite);
+    HIP_TRY(hipGetLastError());
 
-    // the most counted gates any slice has: sizes the per-op arrays.  slice_edge_ptr lives on the device;
-    // at most Q/2 gates fit a slice (a qubit is in one gate per slice)
-    const int32_t max_ops = std::max(1, circ->Q / 2);
+    // the most counted gates any slice has sizes the per-op arrays: the caller's figure if it gave one
+    // (slice_edge_ptr lives on the device), else Q/2 (a qubit is in at most one gate per slice)
+    const int32_t max_ops = std::max(1, circ->max_slice_edges > 0 ? std::min(circ->max_slice_edges, circ->Q / 2) : circ->Q / 2);
     GpArgs p{};
     p.sep = circ->slice_edge_ptr;
     p.edges = circ->edges;
-    p.D = static_cast<const double*>(dt->table);
+    p.D = Dz;
+    p.all_finite = all_finite;
     p.initial = initial;
     p.out = out;
     p.B = B;

@@ -107,7 +107,8 @@ class DeviceCircuit:
         self._visits = _to_dev(ir.visit_records, self.device)
         sptr, sched = ir.scheduled_edges()
         self._sched, self._sched_ptr = _to_dev(sched, self.device), _to_dev(sptr, self.device)
-        self.c = QpCircuit(ir.Q, ir.T, ir.nE, ir.nV, self._sep.data_ptr(), self._edges.data_ptr(),
+        most = int(np.diff(ir.slice_edge_ptr).max()) if ir.T else 0
+        self.c = QpCircuit(ir.Q, ir.T, ir.nE, ir.nV, most, 0, self._sep.data_ptr(), self._edges.data_ptr(),
                            self._la.data_ptr(), self._svp.data_ptr(), self._visits.data_ptr(),
                            self._sched.data_ptr(), self._sched_ptr.data_ptr())
         self.ldq = (ir.Q + 15) // 16 * 16
@@ -234,8 +235,9 @@ class Engine:
             raise ValueError("row pitch must be a multiple of 16 and >= Q")
         if out is None:
             out = torch.empty((B, dc.ir.T + 1, ldq), dtype=torch.uint8, device=self.device)
+        ws = self._workspace(lib().qp_gtrhqa_workspace(dt.C))
         check(lib().qp_gtrhqa_place(C.byref(dc.c), C.byref(dt.f64), initial.data_ptr(), B, ldq, int(cap),
-                                    out.data_ptr(), _stream_ptr(self.device)))
+                                    out.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(self.device)))
         return out
 
 
