@@ -152,6 +152,9 @@ def main():
     ap.add_argument("--partitions", type=int, default=4096, help="partitions per GPU")
     ap.add_argument("--qubits", type=int, default=1024)
     ap.add_argument("--slices", type=int, default=1000)
+    ap.add_argument("--source", choices=["gtrhqa", "walk"], default="gtrhqa",
+                    help="where the partitions come from: the GTRHQA placer itself (on the device, from shuffled "
+                         "starting assignments) or a seeded random walk with move probability --pmove")
     ap.add_argument("--pmove", type=float, default=0.95)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-qubo", action="store_true")
@@ -188,19 +191,50 @@ def main():
     ir = CircuitIR.from_gate_tables(Q, q0, q1)
     dc, eng = DeviceCircuit(ir, dev), Engine(dev)
     C = CX * CY
-    A = make_partitions(torch, dev, B, ir.T, Q, dc.ldq, C, cap, args.pmove, seed=777 + rank)
     out = torch.empty(B, dtype=torch.float64, device=dev)
-    cpu_sample = A[:64, :, :Q].cpu().numpy() if (world == 1 and not args.no_cpu) else None
     alg_bytes = B * ir.T * Q + 4 * ir.nE + 4 * (ir.T + 1) + 8 * B + 8 * C * C
 
-    def run_variant(weights, table="packed"):
-        """Times args.steps passes of the cost path with one weight setting and one form of the distance
-        table ("packed": what the library chooses; "table": look-ups even when a closed form exists)."""
+    def distances(weights):
         random.seed(weight_seed)
         wr = (1.0, 3.0) if weights == "uniform" else (2.0, 2.0)
         arch = multicore(CX, CY, ncm_qubits=4, ncp_qubits=cap, edge_weight_range=wr, network_type="mesh")
         nodes, eu, ev, w = graph_tables(arch.network)
-        D = apsp(len(nodes), eu, ev, w)
+        return wr, apsp(len(nodes), eu, ev, w)
+
+    place = None
+    if args.source == "gtrhqa":
+        # the placer's own output: B GTRHQA placements of the circuit (T+1 rows each) from seeded shuffles
+        # of the block assignment, instance 0 from the block assignment itself; all slices on the device
+        rng = np.random.default_rng(777 + rank)
+        slots = np.repeat(np.arange(C), cap)
+        init = np.zeros((B, dc.ldq), np.uint8)
+        for b in range(B):
+            init[b, :Q] = rng.permutation(slots)[:Q] if b else np.arange(Q) // cap
+        d_init = torch.from_numpy(init).to(dev)
+        dt0 = DistanceTable(distances(args.weights)[1], dev)
+        A = torch.empty((B, ir.T + 1, dc.ldq), dtype=torch.uint8, device=dev)
+        eng.gtrhqa_place(dc, dt0, d_init, cap, out=A)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        eng.gtrhqa_place(dc, dt0, d_init, cap, out=A)
+        torch.cuda.synchronize(dev)
+        t_place = time.perf_counter() - t0
+        moved = float((A[:64, 2:ir.T, :Q] != A[:64, 1:ir.T - 1, :Q]).float().mean().item())
+        place = {"kernel": "k_gtrhqa_place", "instances": B, "seconds": t_place,
+                 "slice_steps_per_s": B * ir.T / t_place, "moved_fraction_between_rows": moved,
+                 "note": "whole placements on the device (bidding rounds included); these rows are the cost workload"}
+        source = (f"GTRHQA placements of this circuit computed on the device from seeded shuffles of the block "
+                  f"assignment ({ir.T + 1} rows each; {moved:.1%} of the qubits change core between consecutive rows)")
+    else:
+        A = make_partitions(torch, dev, B, ir.T, Q, dc.ldq, C, cap, args.pmove, seed=777 + rank)
+        source = (f"random walk from the block assignment, pmove={args.pmove} "
+                  f"(GTRHQA's own output on this circuit changes >95% of the qubits between rows)")
+    cpu_sample = A[:64, :, :Q].cpu().numpy() if (world == 1 and not args.no_cpu) else None
+
+    def run_variant(weights, table="packed"):
+        """Times args.steps passes of the cost path with one weight setting and one form of the distance
+        table ("packed": what the library chooses; "table": look-ups even when a closed form exists)."""
+        wr, D = distances(weights)
         dt = DistanceTable(D, dev)
         closed = table == "packed" and dt.kind == QP_DT_U16 and bool(dt.grid.valid)
         if dt.kind == QP_DT_U16:
@@ -288,12 +322,11 @@ def main():
             "config": {"workload": f"cfg5: layered {Q}q x {ir.T} slices ({ir.nE // ir.T} cx/slice), mesh {CX}x{CY}, "
                                    f"cap {cap}, {primary['weights']} edge weights, {B} partitions/GPU, "
                                    f"cost V3 (HQA/TRHQA/GTRHQA definition)",
-                       "partitions": f"random walk from the block assignment, pmove={args.pmove} "
-                                     f"(GTRHQA's own output on this circuit changes 95% of the qubits between rows)",
+                       "partitions": source,
                        "seeds": {"circuit": circ_seed, "weights": weight_seed, "partitions": "777+rank"},
                        "table": primary["table"]},
             "roofline": primary["roofline"], "mean_cost": primary["mean_cost"], "min_cost": primary["min_cost"],
-            "reduce_ms": primary["reduce_ms"], "cost_matrix": cm, "qubo": qubo,
+            "reduce_ms": primary["reduce_ms"], "gtrhqa_place": place, "cost_matrix": cm, "qubo": qubo,
         }
         # HBM bytes per launch as measured with rocprofv3 PMC counters in a separate run of this workload
         # (profiles/r01_traffic.json; FETCH_SIZE doubled as gfx950 requires for 16-byte-per-lane streams)
