@@ -225,6 +225,21 @@ size_t qp_gtrhqa_workspace(int32_t C);
 int qp_gtrhqa_place(const QpCircuit* circ, const QpDTable* dt, const uint8_t* initial, int64_t B, int32_t ldq,
                     int32_t cap, uint8_t* out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------- device: activity counts */
+
+/* Inter-core events every core takes part in, per partition: hqa_placer.per_core_intercore_activity,
+ * HQA_placer.py:288-321 (== TRHQA_placer.py:586-619).  A as for qp_slice_cost_v3 (dense);
+ * out: dev uint64 [B][C], overwritten. */
+int qp_core_activity(const QpCircuit* circ, const uint8_t* A, int64_t B, int32_t Tp, int32_t ldq, int32_t C,
+                     uint64_t* out, void* stream);
+
+/* Symmetric core x core event counts of the gate-ordered walk: qubo_placer.intercorecommatrix,
+ * Qubo_placer.py:208-245 (the counts, not the heat-map file).  A as for qp_slice_cost_v2 (sparse,
+ * QP_ABSENT allowed).  out: dev int32 [B][C][C], overwritten; status: dev int32 [B], 1 where the
+ * reference would raise (absent qubit of a counted gate, or a qubit placed before and absent now). */
+int qp_comm_matrix(const QpCircuit* circ, const uint8_t* A, int64_t B, int32_t Tp, int32_t ldq, int32_t C,
+                   int32_t* out, int32_t* status, void* stream);
+
 /* ---------------------------------------------------------------- device: QUBO placer */
 
 /* The QUBO placer's objective (Qubo_placer.py:84-133) over binary variables x[t,j,i] (active qubit i

@@ -256,6 +256,62 @@ def cost_v1(slices, gate_q, gate_mr, part, D):
     return total
 
 
+def core_activity(slices, gate_q, gate_mr, part, C):
+    """hqa_placer.per_core_intercore_activity, HQA_placer.py:288-321 (same body in
+    TRHQA_placer.py:586-619): how many inter-core events every core takes part in.  A counted gate whose
+    qubits sit on different cores counts once for each of the two cores; for rows 1..T-1 (from row 1,
+    not 2 as in the cost) every qubit whose core changed counts once for the old and once for the new
+    core.  ``part`` rows are dense (a core per qubit)."""
+    out = [0] * C
+    T = len(slices)
+    for t in range(T):
+        row = part[t]
+        for g in slices[t]:
+            qs = gate_q[g]
+            if len(qs) == 2 and not gate_mr[g]:
+                c1, c2 = row[qs[0]], row[qs[1]]
+                if c1 != c2:
+                    out[c1] += 1
+                    out[c2] += 1
+    for t in range(1, T):
+        prev, cur = part[t - 1], part[t]
+        for q in range(len(cur)):
+            if prev[q] != cur[q]:
+                out[prev[q]] += 1
+                out[cur[q]] += 1
+    return out
+
+
+def comm_matrix(slices, gate_q, gate_mr, part, C):
+    """qubo_placer.intercorecommatrix, Qubo_placer.py:208-245 (the counts; the heat-map it saves is not
+    restated): symmetric C x C event counts of the gate-ordered walk.  Rows hold None for absent qubits;
+    an absent qubit of a counted gate is a KeyError there, a qubit seen before on a core and absent now
+    makes ``list.index(None)`` raise ValueError."""
+    M = [[0] * C for _ in range(C)]
+    last = {}
+    for i, sl in enumerate(slices):
+        row = part[i]
+        for g in sl:
+            qs = gate_q[g]
+            if len(qs) == 2 and not gate_mr[g]:
+                a, b = row[qs[0]], row[qs[1]]
+                if a is None or b is None:
+                    raise CostError("KeyError")
+                if a != b:
+                    M[a][b] += 1
+                    M[b][a] += 1
+            for q in qs:
+                cur = row[q]
+                lq = last.get(q)
+                if lq is not None and cur != lq:
+                    if cur is None:
+                        raise CostError("ValueError")
+                    M[cur][lq] += 1
+                    M[lq][cur] += 1
+                last[q] = cur
+    return M
+
+
 def cost_v4(slices, gate_q, gate_mr, part, H):
     """Qubo_placer.py:177-207: V2 with hop counts, movement looked up as (current, last)."""
     total = 0

@@ -84,6 +84,10 @@ EXPORTS = {
     "qp_gtrhqa_workspace": (C.c_size_t, [C.c_int32]),
     "qp_gtrhqa_place": (C.c_int, [C.POINTER(QpCircuit), C.POINTER(QpDTable), C.c_void_p, C.c_int64, C.c_int32,
                                   C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "qp_core_activity": (C.c_int, [C.POINTER(QpCircuit), C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                                   C.c_void_p, C.c_void_p]),
+    "qp_comm_matrix": (C.c_int, [C.POINTER(QpCircuit), C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                                 C.c_void_p, C.c_void_p, C.c_void_p]),
     "qp_qubo_fields_i32": (C.c_int, [C.POINTER(QpQuboDense), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "qp_qubo_energy_i32": (C.c_int, [C.POINTER(QpQuboDense), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "qp_qubo_anneal": (C.c_int, [C.POINTER(QpQuboStruct), C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_uint64,

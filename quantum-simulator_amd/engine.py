@@ -224,6 +224,25 @@ class Engine:
         return out
 
 
+    def core_activity(self, dc: DeviceCircuit, A, n_cores: int):
+        """Per-core inter-core event counts of B dense partitions: int64 [B, C]."""
+        torch = _torch()
+        B, Tp, ldq = self._check_partitions(dc, A)
+        out = torch.empty((B, n_cores), dtype=torch.int64, device=self.device)
+        check(lib().qp_core_activity(C.byref(dc.c), A.data_ptr(), B, Tp, ldq, int(n_cores), out.data_ptr(),
+                                     _stream_ptr(self.device)))
+        return out
+
+    def comm_matrix(self, dc: DeviceCircuit, A, n_cores: int):
+        """Core x core event counts of B sparse partitions: (int32 [B, C, C], int32 status [B])."""
+        torch = _torch()
+        B, Tp, ldq = self._check_partitions(dc, A)
+        out = torch.empty((B, n_cores, n_cores), dtype=torch.int32, device=self.device)
+        status = torch.empty(B, dtype=torch.int32, device=self.device)
+        check(lib().qp_comm_matrix(C.byref(dc.c), A.data_ptr(), B, Tp, ldq, int(n_cores), out.data_ptr(),
+                                   status.data_ptr(), _stream_ptr(self.device)))
+        return out, status
+
     def gtrhqa_place(self, dc: DeviceCircuit, dt: DistanceTable, initial, cap: int, out=None):
         """B GTRHQA placements on the device.  initial: uint8 [B, ldq] device tensor (row 0 of every
         instance, core indices < C); returns uint8 [B, T+1, ldq]."""

@@ -199,6 +199,19 @@ class _HqaFamily(BasePlacer):
         arr = ctx.partition_array(partition, dense=True, rows=T)
         return ctx.cost(arr, "v3")
 
+    def per_core_intercore_activity(self, circuit, partition, multicore_arch):
+        """HQA_placer.py:288-321 (== TRHQA_placer.py:586-619): {core node: number of inter-core events it
+        takes part in}, counted on the device."""
+        import torch
+        ctx = self._context(circuit, multicore_arch)
+        T = ctx.ir.T
+        if len(partition) < T:
+            raise IndexError("list index out of range")
+        arr = ctx.partition_array(partition, dense=True, rows=T)
+        A = torch.from_numpy(np.ascontiguousarray(arr[None])).to(ctx.device)
+        counts = ctx.eng.core_activity(ctx.dc, A, ctx.arch.C).cpu().numpy()[0]
+        return {node: int(counts[i]) for i, node in enumerate(ctx.arch.nodes)}
+
     @staticmethod
     def _initial(Q, cap):
         # HQA_placer.py:40-44: qubit i (circuit.qubits order) starts on core int(i / cap)
@@ -598,6 +611,34 @@ class qubo_placer(_SparsePlacer):
         if x == float("inf"):
             raise KeyError("qubit missing from the partition where the cost function needs it")
         return int(x)
+
+    def intercorecommatrix(self, circuit, partition, multicore_arch, plot_file=None):
+        """Qubo_placer.py:208-245: symmetric core x core counts of crossing gates and of qubits that
+        changed core since their previous gate, counted on the device.  Returns the numpy matrix (the
+        reference only draws it); with ``plot_file`` the same heat-map is saved there."""
+        import torch
+        ctx = self._context(circuit, multicore_arch)
+        if len(partition) < ctx.ir.T:
+            raise IndexError("list index out of range")
+        arr = ctx.partition_array(partition, dense=False)
+        A = torch.from_numpy(np.ascontiguousarray(arr[None])).to(ctx.device)
+        M, status = ctx.eng.comm_matrix(ctx.dc, A, ctx.arch.C)
+        if int(status.cpu()[0]):
+            raise KeyError("qubit missing from the partition where the walk needs it")
+        M = M.cpu().numpy()[0].astype(int)
+        if plot_file:
+            import matplotlib
+            matplotlib.use("Agg")
+            import matplotlib.pyplot as plt
+            plt.figure(figsize=(8, 6))
+            plt.imshow(M, cmap="hot", interpolation="nearest")
+            plt.colorbar(label="Intercore Communication Count")
+            plt.title("Intercore Communication Matrix")
+            plt.xlabel("QPU index")
+            plt.ylabel("QPU index")
+            plt.savefig(plot_file, bbox_inches="tight")
+            plt.close()
+        return M
 
 
 PLACERS["QUBO"] = qubo_placer

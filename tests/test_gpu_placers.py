@@ -190,3 +190,70 @@ def test_gtrhqa_device_placement_matches_oracle(Q, T, C, cap, B, disconnected):
     for b in range(B):
         want = np.array(O.place_gtrhqa(ir.slices, ir.gate_q, ir.gate_mr, Q, C, cap, Dl, init=inits[b].tolist()), np.uint8)
         assert (got[b, :, :Q] == want).all(), (b, np.argwhere(got[b, :, :Q] != want)[:5])
+
+
+def test_core_activity_matches_reference_fixture():
+    """per_core_intercore_activity on the stored HQA / TRHQA / GTRHQA partitions against what the
+    unmodified reference returned for them (tests/golden/activity.json) and against the restatement."""
+    import json
+    import os
+    from conftest import ROOT
+    from oracle import placer_oracle as O
+    from quantum_simulator_amd.placers import PLACERS
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "activity.json")))
+    seen = 0
+    for name in ALL_CASES:
+        gc = load_case(name)
+        circ, arch = case_circuit(gc), case_arch(gc)
+        nodes = list(arch.network.nodes)
+        placer = PLACERS["HQA"]()
+        ctx = placer._context(circ, arch)
+        for pname, want in gold[name].items():
+            rows = gc.part(pname)
+            part = ctx.rows_to_partition(rows)
+            got = placer.per_core_intercore_activity(circ, part, arch)
+            assert [got[n] for n in nodes] == want, (name, pname)
+            assert O.core_activity(gc.slices, gc.gate_q, gc.gate_mr, rows.tolist(), gc.C) == want
+            seen += 1
+    assert seen >= 40
+
+
+@pytest.mark.parametrize("Q,T,C,B", [(40, 30, 8, 4), (200, 70, 64, 3), (1024, 130, 256, 2), (33, 1, 5, 2)])
+def test_core_activity_and_comm_matrix_random(Q, T, C, B):
+    import torch
+    from oracle import placer_oracle as O
+    from quantum_simulator_amd import engine, layered_gate_arrays
+    from quantum_simulator_amd.timeslices import CircuitIR
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(Q + T)
+    q0, q1, _ = layered_gate_arrays(Q, T, 0.5, seed=Q * 3 + T)
+    keep = rng.random(len(q0)) > 0.3
+    ir = CircuitIR.from_gate_tables(Q, q0[keep], q1[keep])
+    dc, eng = engine.DeviceCircuit(ir, dev), engine.Engine(dev)
+    A = rng.integers(0, C, size=(B, ir.T + 1, dc.ldq), dtype=np.uint8)
+    A[0, 1:] = A[0, :1]
+    got = eng.core_activity(dc, torch.from_numpy(A).to(dev), C).cpu().numpy()
+    for b in range(B):
+        assert got[b].tolist() == O.core_activity(ir.slices, ir.gate_q, ir.gate_mr, A[b, :, :Q].tolist(), C)
+    if C > 255:
+        return
+    # sparse partitions for the gate-ordered walk; instance 1 loses one active qubit (the reference raises)
+    S = np.full((B, ir.T, dc.ldq), 0xFF, np.uint8)
+    for b in range(B):
+        for t in range(ir.T):
+            act = ir.active_qubits(t)
+            S[b, t, act] = rng.integers(0, C, size=len(act))
+    if B > 1 and ir.nV:
+        v = ir.visit_records[int(rng.integers(0, ir.nV))]
+        S[1, v["t"], v["q"]] = 0xFF
+    M, status = eng.comm_matrix(dc, torch.from_numpy(S).to(dev), C)
+    M, status = M.cpu().numpy(), status.cpu().numpy()
+    for b in range(B):
+        rows = [[None if c == 0xFF else int(c) for c in r[:Q]] for r in S[b]]
+        try:
+            want = O.comm_matrix(ir.slices, ir.gate_q, ir.gate_mr, rows, C)
+        except O.CostError:
+            assert status[b] == 1
+            continue
+        assert status[b] == 0 and M[b].tolist() == want
+        assert (M[b] == M[b].T).all()

@@ -4,7 +4,9 @@ import random
 import numpy as np
 import pytest
 
-from conftest import ALL_CASES, SMALL_CASES, load_case
+import os
+
+from conftest import ALL_CASES, ROOT, SMALL_CASES, load_case
 from oracle import placer_oracle as O
 
 BIG = [c for c in ALL_CASES if c not in SMALL_CASES]
@@ -189,3 +191,14 @@ def test_c_oracle_costs_bits(name):
         assert c_oracle.cost_v2(gt, gc.Q, gc.part(p), gc.D, 0) == want, p
         want = float("inf") if pm["v1_error"] else gc.cost_v1(p)
         assert c_oracle.cost_v2(gt, gc.Q, gc.part(p), gc.D, 1) == want, (p, "v1")
+
+
+def test_core_activity_restatement_matches_reference_fixture():
+    """oracle.core_activity against what the unmodified reference returned (activity.json)."""
+    import json
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "activity.json")))
+    for name in ALL_CASES:
+        gc = load_case(name)
+        for pname, want in gold[name].items():
+            got = O.core_activity(gc.slices, gc.gate_q, gc.gate_mr, gc.part(pname).tolist(), gc.C)
+            assert got == want, (name, pname)
