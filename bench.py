@@ -355,7 +355,7 @@ def main():
             tol = 0.0 if kind == QP_DT_U16 else max(1e-12, nterms * 2.0 ** -53)
             sample = cpu_sample
             n_c, t_c = 0, 0.0
-            while t_c < args.cpu_seconds:
+            while t_c < args.cpu_seconds / 2:  # one core
                 k = n_c % len(sample)
                 c0 = time.perf_counter()
                 want = c_oracle.cost_v3(gt, Q, sample[k], D)
@@ -363,6 +363,24 @@ def main():
                 if abs(float(gpu_costs[k]) - want) > tol * abs(want):
                     raise SystemExit(f"parity failure on sample partition {k}: gpu {gpu_costs[k]!r} oracle {want!r}")
                 n_c += 1
+            # the same on every core this process may use (the C call releases the GIL): one thread per core,
+            # each walking the sample for a fixed number of evaluations sized from the one-core rate
+            from concurrent.futures import ThreadPoolExecutor
+            cores = max(1, min(len(os.sched_getaffinity(0)), int(os.environ.get("OMP_NUM_THREADS", "1024"))))
+            per_thread = max(2, int(n_c / t_c * args.cpu_seconds / 2))
+
+            def worker(w):
+                for i in range(per_thread):
+                    k = (w * 7 + i) % len(sample)
+                    want = c_oracle.cost_v3(gt, Q, sample[k], D)
+                    if abs(float(gpu_costs[k]) - want) > tol * abs(want):
+                        raise SystemExit(f"parity failure on sample partition {k}")
+                return per_thread
+
+            c0 = time.perf_counter()
+            with ThreadPoolExecutor(cores) as pool:
+                n_all = sum(pool.map(worker, range(cores)))
+            t_all = time.perf_counter() - c0
             Dl = D.tolist()
             n_py, t_py = 0, 0.0
             while t_py < 3.0 and n_py < len(sample):
@@ -373,10 +391,12 @@ def main():
                 if abs(float(gpu_costs[n_py]) - want) > tol * abs(want):
                     raise SystemExit(f"parity failure (python port) on sample partition {n_py}")
                 n_py += 1
-            res["cpu_baseline"] = {"value": n_c * ir.T / t_c, "unit": "evals/s", "cores": 1, "kind": "port",
-                                   "sample": f"{n_c} evaluations over {len(sample)} of this run's partitions x {ir.T} "
+            res["cpu_baseline"] = {"value": n_all * ir.T / t_all, "unit": "evals/s", "cores": cores, "kind": "port",
+                                   "sample": f"{n_all} evaluations over {len(sample)} of this run's partitions x {ir.T} "
                                              f"slices through oracle/cost_oracle.c (gcc -O2, precomputed distance "
-                                             f"matrix, sequential sums), {t_c:.1f} s; every result checked against the GPU's",
+                                             f"matrix, sequential sums) on {cores} threads, {t_all:.1f} s; every result "
+                                             f"checked against the GPU's",
+                                   "one_core_evals_per_s": n_c * ir.T / t_c,
                                    "python_port_evals_per_s": n_py * ir.T / t_py if n_py else None,
                                    "host_cpus": os.cpu_count(), "affinity": len(os.sched_getaffinity(0))}
         print(json.dumps(res), flush=True)
