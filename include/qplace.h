@@ -6,8 +6,7 @@
  *     place_per_timeslice(circuit, multicore_arch) -> list[dict[qubit -> core]]
  *     per_timeslice_cost(circuit, partition, multicore_arch) -> float
  * Each entry point below replaces one piece of what those methods compute; the comment on each names
- * the reference lines it stands in for.  INTEGRATION.md shows the ctypes stub a maintainer of the
- * reference would add to its placers.
+ * the reference lines it stands in for; quantum-simulator_amd/_lib.py is the complete ctypes binding.
  *
  * Conventions
  *  - Plain pointers and sizes only.  "dev" pointers are HIP device memory owned by the caller;
@@ -16,7 +15,8 @@
  *    (thread-local).  Nothing throws or exits across the ABI.
  *  - Device entry points take a hipStream_t as void* and are asynchronous with respect to the host;
  *    the caller selects the device (hipSetDevice) before the call.
- *  - Core ids are uint8 (C <= 255 real cores + 0xFF = "qubit not in this slice's dict").
+ *  - Core ids are uint8: up to 256 cores for dense partitions; sparse partitions reserve 0xFF for
+ *    "qubit not in this slice's dict" and so hold up to 255.
  */
 #ifndef QPLACE_H
 #define QPLACE_H

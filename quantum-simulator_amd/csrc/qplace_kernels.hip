@@ -515,15 +515,24 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_grid_row(V3Args p) {
                 if (lane_on) *reinterpret_cast<uint4*>(strip + lane * 16) = cur;
                 const int s0 = p.sptr[row];
                 const int nch = (p.sptr[row + 1] - s0) / kWave;
-                // endpoint gathers of the row's gates; a chunk the row does not have stays (0, 0)
+                // endpoint gathers of the row's gates; a chunk the row does not have stays (0, 0).  Rows
+                // with all four chunks take the branch-free path: eight gathers in flight, one wait.
                 uint32_t au[kRowEdgeChunks], av[kRowEdgeChunks];
+                if (nch >= kRowEdgeChunks) {
 #pragma unroll
-                for (int c = 0; c < kRowEdgeChunks; ++c) {
-                    au[c] = 0;
-                    av[c] = 0;
-                    if (c < nch) {
+                    for (int c = 0; c < kRowEdgeChunks; ++c) {
                         au[c] = strip[gates[c] & 0xFFFFu];
                         av[c] = strip[gates[c] >> 16];
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < kRowEdgeChunks; ++c) {
+                        au[c] = 0;
+                        av[c] = 0;
+                        if (c < nch) {
+                            au[c] = strip[gates[c] & 0xFFFFu];
+                            av[c] = strip[gates[c] >> 16];
+                        }
                     }
                 }
                 const uint32_t cw[4] = {cur.x, cur.y, cur.z, cur.w};
