@@ -172,11 +172,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU.  For a rehearsal of the multi-rank control flow on a box with fewer GPUs than ranks,
+    # QP_BENCH_BACKEND=gloo lets ranks share a device (RCCL refuses two ranks on one GPU; gloo does not care)
+    backend = os.environ.get("QP_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev and backend == "nccl":
+        raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({ndev} visible)")
+    dev = torch.device("cuda", local_rank % max(ndev, 1))
+    torch.cuda.set_device(dev)
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from quantum_simulator_amd import layered_gate_arrays
     from quantum_simulator_amd.engine import DeviceCircuit, DistanceTable, Engine, apsp, QP_DT_U16
