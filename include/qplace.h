@@ -276,9 +276,11 @@ typedef struct QpQuboStruct {
     int64_t Npad;
     const int32_t* n;       /* [T] active qubits per slice */
     const int64_t* off;     /* [T+1] */
-    const uint64_t* info;   /* [T*nmax] per (slice, active qubit): bits 0-7 interaction-graph degree,
-                               16-31 first interaction partner (local index), 32-47 index of the same qubit
-                               in slice t+1 (int16, -1: inactive there), 48-63 same for slice t-1 */
+    const uint64_t* info;   /* [T*nmax] per (slice, active qubit): bits 0-7 interaction-graph degree; then
+                               three 16-bit words t' * nmax + i' into the [T][nmax] table of the same
+                               shape, T * nmax meaning "none": 16-31 the first interaction partner
+                               (same slice), 32-47 the same qubit in slice t+1, 48-63 in slice t-1.
+                               T * nmax must stay below 65535. */
     const int32_t* nbr_ptr; /* [T*nmax+1] CSR over interaction partners (used when the degree is > 1) */
     const int16_t* nbr;
     const uint8_t* hops;    /* [C*C] hop counts */

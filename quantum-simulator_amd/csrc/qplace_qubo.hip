@@ -212,14 +212,15 @@ __global__ __launch_bounds__(256) void k_qubo_anneal(SaArgs p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = blockIdx.x * (blockDim.x >> 6) + wave;
     const int T = m.T, C = m.C, cap = m.cap, nmax = m.nmax;
-    // per-wave LDS: mask[T][nmax] u32, load[T][C] i32, slack[T][C] u32
-    const size_t per_wave = ((size_t)T * nmax + 2 * (size_t)T * C) * 4;
-    const size_t hop_bytes = ((size_t)C * C + 15) & ~(size_t)15;
-    uint8_t* hop = smem;  // hop counts, shared by the block's replicas
-    for (int k = threadIdx.x; k < C * C; k += blockDim.x) hop[k] = m.hops[k];
+    // per-wave LDS: mask[T][nmax] u32 + one word that stays zero ("no such qubit"), load[T][C] i32,
+    // slack[T][C] u32
+    const size_t per_wave = ((size_t)T * nmax + 1 + 2 * (size_t)T * C) * 4;
+    const size_t hop_bytes = ((size_t)C * C + 1 + 15) & ~(size_t)15;
+    uint8_t* hop = smem;  // hop counts, shared by the block's replicas; hop[C*C] = 0 for "no bit set"
+    for (int k = threadIdx.x; k <= C * C; k += blockDim.x) hop[k] = k < C * C ? m.hops[k] : 0;
     __syncthreads();
     uint32_t* mask = reinterpret_cast<uint32_t*>(smem + hop_bytes + wave * per_wave);
-    int32_t* load = reinterpret_cast<int32_t*>(mask + (size_t)T * nmax);
+    int32_t* load = reinterpret_cast<int32_t*>(mask + (size_t)T * nmax + 1);
     uint32_t* slack = reinterpret_cast<uint32_t*>(load + (size_t)T * C);
     if (r >= p.R) return;  // after the block-wide barrier above
     int8_t* X = p.Xt + (size_t)r * m.Npad;
@@ -228,6 +229,7 @@ __global__ __launch_bounds__(256) void k_qubo_anneal(SaArgs p) {
     const uint32_t coremask = C >= 32 ? 0xFFFFFFFFu : ((1u << C) - 1u);
 
     // ---- initial state
+    if (lane == 0) mask[(size_t)T * nmax] = 0;
     for (int t = 0; t < T; ++t) {
         const int n = m.n[t];
         const int W = n + cap;
@@ -283,45 +285,46 @@ __global__ __launch_bounds__(256) void k_qubo_anneal(SaArgs p) {
                 uint32_t y = on ? slack[t * C + lj] : 0u;
                 uint32_t* mk = mask + (size_t)(on ? t : 0) * nmax;
                 const size_t tb = (size_t)(on ? t : 0) * nmax;
+                const uint64_t* infp = m.info + tb;
+                const uint8_t* hrow = hop + lj * C;  // hop[lj][.]
+                const uint8_t* hcol = hop + lj;      // hop[.][lj] at stride C
                 const int blocks = (nb + C - 1) / C;
                 for (int mb = 0; mb < blocks; ++mb) {
                     for (int step = 0; step < C; ++step) {
                         int rel = step - lj;
-                        if (rel < 0) rel += C;
+                        rel += (rel >> 31) & C;
                         const int i = mb * C + rel;
                         if (on && i < n) {
                             const uint32_t w = mk[i];
-                            const int bit = (w >> lj) & 1u;
-                            const int d = 1 - 2 * bit;
-                            const int Ai = __popc(w);
-                            // packed per-qubit record: degree | first partner | same qubit in t+1 | in t-1
-                            const uint64_t inf = m.info[tb + i];
-                            const int dg = (int)(inf & 0xFFu);
-                            int lap = dg;
-                            if (dg == 1) {
-                                lap -= 2 * (int)((mk[(int)((inf >> 16) & 0xFFFFu)] >> lj) & 1u);
-                            } else if (dg > 1) {
+                            // packed per-qubit record: degree | word of the first partner | word of the same
+                            // qubit in slice t+1 | in t-1 (words index this replica's mask array; the word
+                            // after the last slice is always zero and stands for "none")
+                            const uint64_t inf = infp[i];
+                            const uint32_t ilo = (uint32_t)inf, ihi = (uint32_t)(inf >> 32);
+                            const int dg = (int)(ilo & 0xFFu);
+                            int lap;
+                            if (dg <= 1) {
+                                lap = dg - 2 * (int)((uint32_t)dg & (mask[ilo >> 16] >> lj));
+                            } else {
+                                lap = dg;
                                 for (int e = m.nbr_ptr[tb + i]; e < m.nbr_ptr[tb + i + 1]; ++e)
                                     lap -= 2 * (int)((mk[m.nbr[e]] >> lj) & 1u);
                             }
+                            // hops to wherever the same qubit sits in the neighbouring slices (one bit per
+                            // word once the state is one-hot)
+                            uint32_t o1 = mask[ihi & 0xFFFFu], o2 = mask[ihi >> 16];
                             int mv = 0;
-                            const int ix = (int)(int16_t)((inf >> 32) & 0xFFFFu), ip = (int)(int16_t)((inf >> 48) & 0xFFFFu);
-                            if (ix >= 0) {
-                                uint32_t o = mask[(size_t)(t + 1) * nmax + ix];
-                                while (o) {
-                                    const int l = __ffs(o) - 1;
-                                    o &= o - 1;
-                                    mv += hop[lj * C + l];
-                                }
+                            while (o1) {
+                                mv += hrow[__builtin_ctz(o1)];
+                                o1 &= o1 - 1;
                             }
-                            if (ip >= 0) {
-                                uint32_t o = mask[(size_t)(t - 1) * nmax + ip];
-                                while (o) {
-                                    const int l = __ffs(o) - 1;
-                                    o &= o - 1;
-                                    mv += hop[l * C + lj];
-                                }
+                            while (o2) {
+                                mv += hcol[__builtin_ctz(o2) * C];
+                                o2 &= o2 - 1;
                             }
+                            const int bit = (w >> lj) & 1u;
+                            const int d = 1 - 2 * bit;
+                            const int Ai = __popc(w);
                             const int dE = 4 * d * (2 * (Ai - 1) + d) + 4 * d * (2 * L + d) + 10 * d * (lap + mv);
                             if (metropolis(dE, beta, rng)) {
                                 mk[i] = w ^ (1u << lj);
@@ -421,7 +424,9 @@ extern "C" int qp_qubo_anneal(const QpQuboStruct* m, int32_t R, int32_t sweeps, 
     if (R <= 0 || sweeps < 0 || !(beta_hot > 0) || !(beta_cold > 0)) return qp::fail(QP_EINVAL, "qp_qubo_anneal: bad R/sweeps/beta");
     if (!m->n || !m->off || !m->info || !m->nbr_ptr || !m->hops)
         return qp::fail(QP_EINVAL, "qp_qubo_anneal: model tables missing");
-    const size_t per_wave = ((size_t)m->T * m->nmax + 2 * (size_t)m->T * m->C) * 4;
+    if ((int64_t)m->T * m->nmax > 65534)
+        return qp::fail(QP_EINVAL, "qp_qubo_anneal: T * nmax must stay below 65535 (16-bit word indices in info)");
+    const size_t per_wave = ((size_t)m->T * m->nmax + 1 + 2 * (size_t)m->T * m->C) * 4;
     int waves = 4;
     while (waves > 1 && per_wave * waves > 64 * 1024) waves >>= 1;
     if (per_wave * waves > 160 * 1024) return qp::fail(QP_EINVAL, "qp_qubo_anneal: model too large for LDS (%zu bytes per replica)", per_wave);
@@ -435,7 +440,7 @@ extern "C" int qp_qubo_anneal(const QpQuboStruct* m, int32_t R, int32_t sweeps, 
     a.beta_hot = (float)beta_hot;
     a.beta_ratio_log = (float)std::log(beta_cold / beta_hot);
     a.seed = seed;
-    const size_t lds = per_wave * waves + (((size_t)m->C * m->C + 15) & ~(size_t)15);
+    const size_t lds = per_wave * waves + (((size_t)m->C * m->C + 1 + 15) & ~(size_t)15);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_qubo_anneal), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     k_qubo_anneal<<<(R + waves - 1) / waves, waves * 64, lds, static_cast<hipStream_t>(stream_)>>>(a);
     HIP_TRY(hipGetLastError());

@@ -264,15 +264,20 @@ class DeviceQubo:
                 ptr[t * nmax + i + 1] = len(nbr)
         if m.H.max() > 255:
             raise ValueError("hop counts above 255 are not supported")
-        first = np.zeros((m.T, nmax), np.uint64)
+        # word indices into the [T][nmax] table; T * nmax = "none"
+        none = m.T * nmax
+        if none > 65534:
+            raise ValueError("T * max active qubits must stay below 65535")
+        first = np.full((m.T, nmax), none, np.uint64)
         for t in range(m.T):
             for i in range(int(m.n[t])):
                 a, b = ptr[t * nmax + i], ptr[t * nmax + i + 1]
                 if b > a:
-                    first[t, i] = nbr[a]
-        info = (deg.astype(np.uint64) | (first << np.uint64(16))
-                | ((nxt.astype(np.int64) & 0xFFFF).astype(np.uint64) << np.uint64(32))
-                | ((prv.astype(np.int64) & 0xFFFF).astype(np.uint64) << np.uint64(48)))
+                    first[t, i] = t * nmax + nbr[a]
+        trow = (np.arange(m.T, dtype=np.int64) * nmax)[:, None]
+        nxt_w = np.where(nxt >= 0, trow + nmax + nxt, none).astype(np.uint64)
+        prv_w = np.where(prv >= 0, trow - nmax + prv, none).astype(np.uint64)
+        info = (deg.astype(np.uint64) | (first << np.uint64(16)) | (nxt_w << np.uint64(32)) | (prv_w << np.uint64(48)))
         self.struct = _lib.QpQuboStruct(m.T, m.C, m.cap, nmax, m.Npad, up(m.n.astype(np.int32)).data_ptr(),
                                         off.data_ptr(), up(info).data_ptr(), up(ptr).data_ptr(),
                                         up(np.asarray(nbr if nbr else [0], np.int16)).data_ptr(),
