@@ -44,30 +44,34 @@ struct GemmArgs {
     int32_t Npad, R;
 };
 
-template <bool ENERGY>
-__global__ __launch_bounds__(256) void k_qubo_gemm(GemmArgs p) {
+// WN = MFMA tiles per wave along the replica axis: 2 (128 replicas per workgroup) or 4 (256).  With 4, a
+// wave feeds 8 MFMAs from 6 fragment reads instead of 4 from 4, which is what the LDS read rate allows.
+template <bool ENERGY, int WN>
+__global__ __launch_bounds__(256, 2) void k_qubo_gemm(GemmArgs p) {
+    constexpr int kCols = 64 * WN;  // replicas per workgroup
     __shared__ __align__(16) int8_t sA[kTile * kPitch];
-    __shared__ __align__(16) int8_t sB[kTile * kPitch];
+    __shared__ __align__(16) int8_t sB[kCols * kPitch];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int rowtile = blockIdx.x, coltile = blockIdx.y;
     const int t = p.tile_slice[rowtile];
     const int64_t v0 = (int64_t)rowtile * kTile;     // first variable (padded axis) of this tile
     const int64_t vrow = v0 - p.off[t];              // row inside the slice's blocks
-    const int r0 = coltile * kTile;
+    const int r0 = coltile * kCols;
 
-    v16i acc[2][2];
+    v16i acc[2][WN];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < WN; ++b)
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[a][b][k] = 0;
 
-    // staging: thread -> (row = tid / 8 + 32 i, 16-byte piece = tid % 8) of a 128 x 128 byte tile; the
+    // staging: thread -> (row = tid / 8 + 32 i, 16-byte piece = tid % 8) of a (rows x 128)-byte tile; the
     // next tile's global loads are issued before the current tile's MFMAs so they overlap
     const int srow = tid >> 3, spiece = tid & 7;
-    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    // (named registers and a macro: staging arrays, or a lambda capturing them, end up in scratch memory)
+    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3, rb4, rb5, rb6, rb7;
 #define QP_LOAD_TILE(Ab, Bb, ld, k0)                                                                          \
     do {                                                                                                      \
         const int8_t* pa_ = (Ab) + (size_t)srow * (ld) + (k0) + spiece * 16;                                  \
@@ -80,6 +84,12 @@ __global__ __launch_bounds__(256) void k_qubo_gemm(GemmArgs p) {
         rb1 = *reinterpret_cast<const uint4*>(pb_ + (size_t)32 * p.Npad);                                     \
         rb2 = *reinterpret_cast<const uint4*>(pb_ + (size_t)64 * p.Npad);                                     \
         rb3 = *reinterpret_cast<const uint4*>(pb_ + (size_t)96 * p.Npad);                                     \
+        if constexpr (WN == 4) {                                                                              \
+            rb4 = *reinterpret_cast<const uint4*>(pb_ + (size_t)128 * p.Npad);                                \
+            rb5 = *reinterpret_cast<const uint4*>(pb_ + (size_t)160 * p.Npad);                                \
+            rb6 = *reinterpret_cast<const uint4*>(pb_ + (size_t)192 * p.Npad);                                \
+            rb7 = *reinterpret_cast<const uint4*>(pb_ + (size_t)224 * p.Npad);                                \
+        }                                                                                                     \
     } while (0)
     for (int sg = p.seg_ptr[t]; sg < p.seg_ptr[t + 1]; ++sg) {
         const QpQuboSeg seg = p.segs[sg];
@@ -99,23 +109,29 @@ __global__ __launch_bounds__(256) void k_qubo_gemm(GemmArgs p) {
                 *reinterpret_cast<uint4*>(wb + 32 * kPitch) = rb1;
                 *reinterpret_cast<uint4*>(wb + 64 * kPitch) = rb2;
                 *reinterpret_cast<uint4*>(wb + 96 * kPitch) = rb3;
+                if constexpr (WN == 4) {
+                    *reinterpret_cast<uint4*>(wb + 128 * kPitch) = rb4;
+                    *reinterpret_cast<uint4*>(wb + 160 * kPitch) = rb5;
+                    *reinterpret_cast<uint4*>(wb + 192 * kPitch) = rb6;
+                    *reinterpret_cast<uint4*>(wb + 224 * kPitch) = rb7;
+                }
             }
             __syncthreads();
             if (k0 + kBK < seg.K) QP_LOAD_TILE(Ab, Bb, seg.ld, k0 + kBK);
 #pragma unroll
             for (int kk = 0; kk < kBK / 32; ++kk) {
-                v4i fa[2], fb[2];
+                v4i fa[2], fb[WN];
                 const int koff = kk * 32 + (lane >> 5) * 16;
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
                     fa[a] = *reinterpret_cast<const v4i*>(sA + (wm * 64 + a * 32 + (lane & 31)) * kPitch + koff);
 #pragma unroll
-                for (int b = 0; b < 2; ++b)
-                    fb[b] = *reinterpret_cast<const v4i*>(sB + (wn * 64 + b * 32 + (lane & 31)) * kPitch + koff);
+                for (int b = 0; b < WN; ++b)
+                    fb[b] = *reinterpret_cast<const v4i*>(sB + (wn * 32 * WN + b * 32 + (lane & 31)) * kPitch + koff);
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
-                    for (int b = 0; b < 2; ++b)
+                    for (int b = 0; b < WN; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[a], fb[b], acc[a][b], 0, 0, 0);
             }
         }
@@ -128,8 +144,8 @@ __global__ __launch_bounds__(256) void k_qubo_gemm(GemmArgs p) {
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const int col = r0 + wn * 64 + b * 32 + (lane & 31);
+            for (int b = 0; b < WN; ++b) {
+                const int col = r0 + wn * 32 * WN + b * 32 + (lane & 31);
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
                     const int64_t row = v0 + wm * 64 + a * 32 + (k & 3) + 8 * (k >> 2) + 4 * h;
@@ -138,8 +154,8 @@ __global__ __launch_bounds__(256) void k_qubo_gemm(GemmArgs p) {
             }
     } else {
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int col = r0 + wn * 64 + b * 32 + (lane & 31);
+        for (int b = 0; b < WN; ++b) {
+            const int col = r0 + wn * 32 * WN + b * 32 + (lane & 31);
             int s = 0;
 #pragma unroll
             for (int a = 0; a < 2; ++a)
@@ -398,8 +414,10 @@ GemmArgs gemm_args(const QpQuboDense* m, const int8_t* Xt, int32_t R, int32_t* o
 
 extern "C" int qp_qubo_fields_i32(const QpQuboDense* m, const int8_t* Xt, int32_t R, int32_t* F, void* stream_) {
     if (int rc = check_dense("qp_qubo_fields_i32", m, Xt, R, F)) return rc;
-    const dim3 grid(m->Npad / kTile, R / kTile);
-    k_qubo_gemm<false><<<grid, 256, 0, static_cast<hipStream_t>(stream_)>>>(gemm_args(m, Xt, R, F));
+    if (R % 256 == 0)
+        k_qubo_gemm<false, 4><<<dim3(m->Npad / kTile, R / 256), 256, 0, static_cast<hipStream_t>(stream_)>>>(gemm_args(m, Xt, R, F));
+    else
+        k_qubo_gemm<false, 2><<<dim3(m->Npad / kTile, R / 128), 256, 0, static_cast<hipStream_t>(stream_)>>>(gemm_args(m, Xt, R, F));
     HIP_TRY(hipGetLastError());
     return QP_OK;
 }
@@ -408,8 +426,10 @@ extern "C" int qp_qubo_energy_i32(const QpQuboDense* m, const int8_t* Xt, int32_
     if (int rc = check_dense("qp_qubo_energy_i32", m, Xt, R, energy)) return rc;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     HIP_TRY(hipMemsetAsync(energy, 0, (size_t)R * sizeof(int32_t), stream));
-    const dim3 grid(m->Npad / kTile, R / kTile);
-    k_qubo_gemm<true><<<grid, 256, 0, stream>>>(gemm_args(m, Xt, R, energy));
+    if (R % 256 == 0)
+        k_qubo_gemm<true, 4><<<dim3(m->Npad / kTile, R / 256), 256, 0, stream>>>(gemm_args(m, Xt, R, energy));
+    else
+        k_qubo_gemm<true, 2><<<dim3(m->Npad / kTile, R / 128), 256, 0, stream>>>(gemm_args(m, Xt, R, energy));
     HIP_TRY(hipGetLastError());
     k_qubo_finish<<<(R + 255) / 256, 256, 0, stream>>>(energy, R, m->constant);
     HIP_TRY(hipGetLastError());
