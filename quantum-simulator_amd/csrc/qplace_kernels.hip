@@ -365,18 +365,29 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_row(V3Args p) {
 
         // Loads are unconditional (addresses clamped into the item / the gate list) so that the row
         // loop has no divergent control flow; what they return for a row past the end is never used.
+        // Bases are wave-uniform, the per-lane part of every address is fixed.
         const int lane16 = lane_on ? lane * 16 : 0;
+        const uint32_t* sched_lane = p.edges_sched + lane;
         auto fetch_row = [&](int row) -> uint4 {
-            return *reinterpret_cast<const uint4*>(base + (size_t)min(row, r1 - 1) * ldq + lane16);
+            const uint8_t* rp = base + (size_t)min(row, r1 - 1) * ldq;
+            return *reinterpret_cast<const uint4*>(rp + lane16);
         };
         // gate `lane` of chunk c of the row (a later slice's gates or padding if the row has fewer
         // chunks: the consumer skips those, so nothing here waits on a loaded value)
         auto fetch_gate = [&](int row, int c) -> uint32_t {
-            return p.edges_sched[p.sptr[min(row, r1 - 1)] + c * kWave + lane];
+            const uint32_t* gp = sched_lane + p.sptr[min(row, r1 - 1)];
+            return gp[c * kWave];
         };
 
-        uint4 prv = make_uint4(0, 0, 0, 0);
-        if (r0 >= 1 && lane_on) prv = *reinterpret_cast<const uint4*>(base + (size_t)(r0 - 1) * ldq + lane * 16);
+        // previous row with the bytes of qubits that do not exist zeroed (keep is zero for unused lanes)
+        uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+        if (r0 >= 1) {
+            const uint4 prv = fetch_row(r0 - 1);
+            p0 = prv.x & keep[0];
+            p1 = prv.y & keep[1];
+            p2 = prv.z & keep[2];
+            p3 = prv.w & keep[3];
+        }
         uint4 ring[AHEAD];
         uint32_t gring[AHEAD][kRowEdgeChunks];
 #pragma unroll
@@ -405,20 +416,26 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_row(V3Args p) {
                 const int s0 = p.sptr[row];
                 const int nch = (p.sptr[row + 1] - s0) / kWave;
                 uint32_t au[kRowEdgeChunks], av[kRowEdgeChunks];
+                if (nch >= kRowEdgeChunks) {
 #pragma unroll
-                for (int c = 0; c < kRowEdgeChunks; ++c) {
-                    const uint32_t g = c < nch ? gates[c] : 0u;
-                    au[c] = strip[g & 0xFFFFu];
-                    av[c] = strip[g >> 16];
+                    for (int c = 0; c < kRowEdgeChunks; ++c) {
+                        au[c] = strip[gates[c] & 0xFFFFu];
+                        av[c] = strip[gates[c] >> 16];
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < kRowEdgeChunks; ++c) {
+                        const uint32_t g = c < nch ? gates[c] : 0u;
+                        au[c] = strip[g & 0xFFFFu];
+                        av[c] = strip[g >> 16];
+                    }
                 }
-                const bool mv = lane_on && row >= 2;
-                const uint32_t c0 = mv ? cur.x & keep[0] : 0u, p0 = mv ? prv.x & keep[0] : 0u;
-                const uint32_t c1 = mv ? cur.y & keep[1] : 0u, p1 = mv ? prv.y & keep[1] : 0u;
-                const uint32_t c2 = mv ? cur.z & keep[2] : 0u, p2 = mv ? prv.z & keep[2] : 0u;
-                const uint32_t c3 = mv ? cur.w & keep[3] : 0u, p3 = mv ? prv.w & keep[3] : 0u;
-                const bool moved = ((c0 ^ p0) | (c1 ^ p1) | (c2 ^ p2) | (c3 ^ p3)) != 0;
-                if (__builtin_amdgcn_ballot_w64(moved) != 0)
-                    acc += (four(p0, c0) + four(p1, c1)) + (four(p2, c2) + four(p3, c3));
+                const uint32_t c0 = cur.x & keep[0], c1 = cur.y & keep[1], c2 = cur.z & keep[2], c3 = cur.w & keep[3];
+                if (row >= 2) {  // movement is charged from row 2 on
+                    const bool moved = ((c0 ^ p0) | (c1 ^ p1) | (c2 ^ p2) | (c3 ^ p3)) != 0;
+                    if (__builtin_amdgcn_ballot_w64(moved) != 0)
+                        acc += (four(p0, c0) + four(p1, c1)) + (four(p2, c2) + four(p3, c3));
+                }
                 {
                     Acc s = 0;
 #pragma unroll
@@ -426,10 +443,13 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_row(V3Args p) {
                     acc += s;
                 }
                 for (int c = kRowEdgeChunks; c < nch; ++c) {
-                    const uint32_t g = p.edges_sched[s0 + c * kWave + lane];
+                    const uint32_t g = sched_lane[s0 + c * kWave];
                     acc += pair_at(strip[g & 0xFFFFu], strip[g >> 16]);
                 }
-                prv = cur;
+                p0 = c0;
+                p1 = c1;
+                p2 = c2;
+                p3 = c3;
             }
         }
         const double s = wave_sum(acc);
