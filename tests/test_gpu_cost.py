@@ -313,3 +313,39 @@ def test_cost_v3_full_size_against_c_oracle(gpu, integer):
     # size-independent property: the cost is additive over a split of the timeline when the second
     # part starts with a repeated row (no movement is charged for rows 0 and 1 of either part)
     assert got.tobytes() == eng.cost_v3(dc, dt, torch.from_numpy(A).to(dev)).cpu().numpy().tobytes()
+
+
+def test_degenerate_circuits(gpu):
+    """No gates at all (zero slices) and one-qubit gates only (slices without counted gates): what the
+    reference's loops do with them — nothing, or movement only."""
+    torch, engine, eng, dev = gpu
+    from quantum_simulator_amd.timeslices import CircuitIR
+    rng = np.random.default_rng(3)
+    C, cap = 4, 3
+    D = engine.apsp(C, [0, 1, 2], [1, 2, 3], [1.5, 2.0, 2.5])
+    dt = engine.DistanceTable(D, dev)
+    # zero slices
+    ir = CircuitIR.from_gate_tables(5, np.array([], np.int32), np.array([], np.int32))
+    dc = engine.DeviceCircuit(ir, dev)
+    A = torch.from_numpy(rng.integers(0, C, size=(2, 3, dc.ldq), dtype=np.uint8)).to(dev)
+    assert eng.cost_v3(dc, dt, A).cpu().tolist() == [0.0, 0.0]
+    assert eng.cost_v2(dc, dt, A, engine.QP_V2).cpu().tolist() == [0.0, 0.0]
+    assert eng.core_activity(dc, A, C).cpu().numpy().sum() == 0
+    init = torch.from_numpy(rng.integers(0, C, size=(2, dc.ldq), dtype=np.uint8)).to(dev)
+    rows = eng.gtrhqa_place(dc, dt, init, cap)
+    assert rows.shape == (2, 1, dc.ldq) and (rows[:, 0] == init).all()
+    # one-qubit gates only: Q = 1100 takes the long-row kernels, Q = 20 the short-row ones
+    for Q in (20, 1100):
+        q0 = rng.integers(0, Q, size=6 * Q).astype(np.int32)
+        ir = CircuitIR.from_gate_tables(Q, q0, np.full(len(q0), -1, np.int32))
+        assert ir.nE == 0 and ir.T > 2
+        dc = engine.DeviceCircuit(ir, dev)
+        An = rng.integers(0, C, size=(2, ir.T, dc.ldq), dtype=np.uint8)
+        got = eng.cost_v3(dc, dt, torch.from_numpy(An).to(dev)).cpu().numpy()
+        for b in range(2):
+            want = O.cost_v3(ir.slices, ir.gate_q, ir.gate_mr, An[b, :, :Q].tolist(), D.tolist())
+            assert _close(got[b], want, False)
+        init = np.zeros((2, dc.ldq), np.uint8)
+        init[:, :Q] = rng.integers(0, C, size=(2, Q))
+        rows = eng.gtrhqa_place(dc, dt, torch.from_numpy(init).to(dev), 600).cpu().numpy()
+        assert (rows == init[:, None, :]).all()  # nothing to place: every row repeats the start
