@@ -748,12 +748,30 @@ __device__ inline double pymax(double a, double b) { return b > a ? b : a; }  //
 // One workgroup = one instance x kCmOps consecutive ops; thread j owns available-core column j.
 // What depends on the op only (the cores of its two qubits and of its up to six look-ahead partners)
 // hangs on a chain of dependent loads (op -> gate -> qubit -> core).  kCmOps * 8 threads walk one chain
-// each, side by side, and leave the eight cores in LDS; after that every entry costs two coalesced
-// distance loads, two broadcast LDS reads, the reference's arithmetic and one coalesced 8-byte store.
-constexpr int kCmOps = 16;
+// each, side by side, and leave the eight cores in LDS.  The look-ahead attraction of an op is the same
+// sum for every core that holds none of its partners (all terms take the 0.3 branch), so it is formed
+// once per op, in the reference's order; a 256-bit mask per op marks the few cores that do hold a
+// partner, and only those entries walk the six slots.  After that an entry costs two coalesced distance
+// loads, three broadcast LDS reads, the reference's clamp arithmetic and one coalesced 8-byte store.
+constexpr int kCmOps = 32;
 
+__device__ inline double cm_attraction(const int32_t* pc, int32_t c) {
+    double att = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        if (pc[k] >= 0) {
+            const double w = k < 2 ? 0.5 : (k < 4 ? 0.25 : 0.125);
+            att += (pc[k] == c) ? w * 0.9 : w * 0.3;
+        }
+    }
+    return att;
+}
+
+template <int KINDC>
 __global__ __launch_bounds__(256) void k_cost_matrix(CmArgs p) {
     __shared__ __align__(16) int32_t opinfo[kCmOps][8];  // [0..5] partner cores (-1 = none), [6] a1, [7] a2
+    __shared__ double att_far[kCmOps];                   // attraction seen from a core that holds no partner
+    __shared__ uint32_t near_mask[kCmOps][8];            // bit c: core c holds a look-ahead partner
     const int64_t b = blockIdx.y;
     const int n_ops = p.n_ops[b], n_av = p.n_avail[b];
     const int i0 = blockIdx.x * kCmOps;
@@ -767,39 +785,61 @@ __global__ __launch_bounds__(256) void k_cost_matrix(CmArgs p) {
         if (i < i1) {
             const int eid = p.ops[(size_t)b * p.max_ops + i];
             int q;
-            if (k < 6) q = p.kind == QP_CM_GTRHQA ? -1 : p.lookahead[(size_t)eid * 6 + k];
+            if (k < 6) q = KINDC == QP_CM_GTRHQA ? -1 : p.lookahead[(size_t)eid * 6 + k];
             else q = k == 6 ? p.edges[eid].u : p.edges[eid].v;
             if (q >= 0) v = a[q];
         }
         opinfo[threadIdx.x >> 3][k] = v;
     }
     __syncthreads();
+    if (threadIdx.x < kCmOps) {
+        const int32_t* pc = opinfo[threadIdx.x];
+        att_far[threadIdx.x] = cm_attraction(pc, -2);  // -2 equals no core
+        uint32_t m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            if (pc[k] >= 0) {
+#pragma unroll
+                for (int w = 0; w < 8; ++w) m[w] |= (pc[k] >> 5) == w ? 1u << (pc[k] & 31) : 0u;
+            }
+#pragma unroll
+        for (int w = 0; w < 8; ++w) near_mask[threadIdx.x][w] = m[w];
+    }
+    __syncthreads();
     for (int j = threadIdx.x; j < n_av; j += blockDim.x) {
         const int32_t c = p.avail[(size_t)b * C + j];
+        const double* Dc = p.D + c;  // column c of the table
         double* outp = p.out + ((size_t)b * p.max_ops + i0) * C + j;
-        for (int i = 0; i < i1 - i0; ++i) {
-            const int4 pc03 = *reinterpret_cast<const int4*>(&opinfo[i][0]);
-            const int4 pc47 = *reinterpret_cast<const int4*>(&opinfo[i][4]);
-            const int32_t a1 = pc47.z, a2 = pc47.w;
-            const double d1 = p.D[a1 * C + c], d2 = p.D[a2 * C + c];
+        // four ops at a time: their eight distance loads are issued before any of the arithmetic
+        const int nloc = i1 - i0;
+        for (int ib = 0; ib < nloc; ib += 4) {
+            int32_t a1s[4], a2s[4];
+            double d1s[4], d2s[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = min(ib + u, nloc - 1);
+                a1s[u] = opinfo[i][6];
+                a2s[u] = opinfo[i][7];
+                d1s[u] = Dc[a1s[u] * C];
+                d2s[u] = Dc[a2s[u] * C];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+            const int i = ib + u;
+            if (i >= nloc) break;
+            const int32_t a1 = a1s[u], a2 = a2s[u];
+            const double d1 = d1s[u], d2 = d2s[u];
             double r;
-            if (p.kind == QP_CM_GTRHQA) {
+            if constexpr (KINDC == QP_CM_GTRHQA) {
                 // a core whose label is 0 is "falsy" in the reference: leaving core 0 costs nothing
                 double cost = 0.0;
                 if (a1 != 0 && a1 != c) cost += d1;
                 if (a2 != 0 && a2 != c) cost += d2;
                 r = cost;
             } else {
-                const int32_t pc[6] = {pc03.x, pc03.y, pc03.z, pc03.w, pc47.x, pc47.y};
-                double att = 0.0;
-#pragma unroll
-                for (int k = 0; k < 6; ++k) {
-                    if (pc[k] >= 0) {
-                        const double w = k < 2 ? 0.5 : (k < 4 ? 0.25 : 0.125);
-                        att += (pc[k] == c) ? w * 0.9 : w * 0.3;
-                    }
-                }
-                if (p.kind == QP_CM_HQA) {
+                double att = att_far[i];
+                if ((near_mask[i][c >> 5] >> (c & 31)) & 1u) att = cm_attraction(opinfo[i], c);
+                if constexpr (KINDC == QP_CM_HQA) {
                     const double m = (double)((a1 != c) + (a2 != c));
                     r = pymax(0.1, pymax(0.1, m - att));
                 } else {
@@ -815,6 +855,7 @@ __global__ __launch_bounds__(256) void k_cost_matrix(CmArgs p) {
                 }
             }
             outp[(size_t)i * C] = r;
+            }
         }
     }
 }
@@ -1089,7 +1130,10 @@ extern "C" int qp_cost_matrix(int32_t kind, const QpCircuit* circ, const QpDTabl
     p.max_ops = max_ops;
     p.kind = kind;
     const dim3 grid((unsigned)((max_ops + kCmOps - 1) / kCmOps), (unsigned)B);
-    k_cost_matrix<<<grid, 256, 0, static_cast<hipStream_t>(stream_)>>>(p);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (kind == QP_CM_HQA) k_cost_matrix<QP_CM_HQA><<<grid, 256, 0, stream>>>(p);
+    else if (kind == QP_CM_TRHQA) k_cost_matrix<QP_CM_TRHQA><<<grid, 256, 0, stream>>>(p);
+    else k_cost_matrix<QP_CM_GTRHQA><<<grid, 256, 0, stream>>>(p);
     HIP_TRY(hipGetLastError());
     return QP_OK;
 }
