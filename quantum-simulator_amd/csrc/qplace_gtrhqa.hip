@@ -18,9 +18,7 @@
 
 namespace {
 
-constexpr int kThreads = 1024;  // 16 waves: a round's argmins (one wave each) run side by side
 constexpr int kWave = 64;
-constexpr int kWaves = kThreads / kWave;
 constexpr double kBig = 1e12;  // what a non-finite entry counts as in an argmin (GTRHQA_placer.py:139)
 
 struct GpArgs {
@@ -33,7 +31,7 @@ struct GpArgs {
     int64_t B;
     int32_t T, Q, ldq, C, cap, max_ops;
     // byte offsets into dynamic LDS
-    uint32_t off_rows, off_occ, off_best, off_win, off_bid, off_target, off_uv, off_a12, off_flags, off_cores;
+    uint32_t off_rows, off_occ, off_best, off_win, off_bid, off_target, off_uv, off_a12, off_flags, off_cores, off_need;
 };
 
 struct OpFlags {
@@ -54,6 +52,13 @@ __device__ inline void lexmin_step(unsigned long long& key, uint32_t& idx) {
         key = okey;
         idx = oidx;
     }
+}
+// Same over each 16-lane row: every lane of a row ends up with its row's minimum.
+__device__ inline void lexmin_row(unsigned long long& key, uint32_t& idx) {
+    lexmin_step<0xB1, 0xF>(key, idx);   // quad_perm [1,0,3,2]
+    lexmin_step<0x4E, 0xF>(key, idx);   // quad_perm [2,3,0,1]
+    lexmin_step<0x141, 0xF>(key, idx);  // row_half_mirror
+    lexmin_step<0x140, 0xF>(key, idx);  // row_mirror
 }
 __device__ inline void lexmin_wave(unsigned long long& key, uint32_t& idx) {
     lexmin_step<0xB1, 0xF>(key, idx);   // quad_perm [1,0,3,2]
@@ -91,7 +96,11 @@ __global__ void k_gtrhqa_prepare(const double* D, int C, double* Dz, int32_t* al
     if (threadIdx.x == 0) *all_finite = bad ? 0 : 1;
 }
 
+// kThreads = 1024: 16 waves share an instance's bidding (shortest time for one placement);
+// kThreads = 256: more instances resident per CU (highest throughput for large batches).
+template <int kThreads>
 __global__ __launch_bounds__(kThreads) void k_gtrhqa_place(GpArgs p) {
+    constexpr int kWaves = kThreads / kWave;
     extern __shared__ __align__(16) uint8_t smem[];
     __shared__ int s_nops, s_nav, s_nleft, s_nfree, s_flag, s_wave_cnt[kWaves], s_base;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
@@ -107,6 +116,7 @@ __global__ __launch_bounds__(kThreads) void k_gtrhqa_place(GpArgs p) {
     OpFlags* flags = reinterpret_cast<OpFlags*>(smem + p.off_flags);   // [max_ops]
     uint8_t* avail = smem + p.off_cores;                               // [C] core id of column j
     uint8_t* cfree = avail + C;                                        // [C] by column
+    uint16_t* need_list = reinterpret_cast<uint16_t*>(smem + p.off_need);  // [max_ops] ops that must bid again
 
     // all distances finite: then every entry is, and the "nothing finite left" test never fires
     const bool dfinite = *p.all_finite != 0;
@@ -192,10 +202,14 @@ __global__ __launch_bounds__(kThreads) void k_gtrhqa_place(GpArgs p) {
             }
             const int nops = s_nops, nav = s_nav;
             if (nops > 0 && nav > 0) {
-                // this lane's columns lane, lane + 64, ...: element offset of the core inside a table row
-                uint32_t coff[4];
+                // A 16-lane row of a wave serves one bidding op; lane l of the row looks at columns l, l + 16, ...
+                // Their cores, four to a register:
+                const int l16 = lane & 15, rowi = lane >> 4;
+                const int nit = (nav + 15) >> 4;
+                uint32_t cpk[4] = {0, 0, 0, 0};
 #pragma unroll
-                for (int jb = 0; jb < 4; ++jb) coff[jb] = avail[min(jb * kWave + lane, nav - 1)];
+                for (int it = 0; it < 16; ++it)
+                    cpk[it >> 2] |= (uint32_t)avail[min(it * 16 + l16, nav - 1)] << (8 * (it & 3));
                 if (tid == 0) {
                     s_nleft = nops;
                     s_nfree = nav;
@@ -221,39 +235,61 @@ __global__ __launch_bounds__(kThreads) void k_gtrhqa_place(GpArgs p) {
                         __syncthreads();
                         if (!go) break;
                     }
-                    // every open op without a standing bid looks for its cheapest free core (first minimum)
-                    uint32_t fmask = 0;  // bit jb: this lane's column jb * 64 + lane exists and is free
-#pragma unroll
-                    for (int jb = 0; jb < 4; ++jb) {
-                        const int j = jb * kWave + lane;
-                        if (j < nav && cfree[j]) fmask |= 1u << jb;
+                    // the ops without a standing bid, in op order
+                    if (tid == 0) s_base = 0;
+                    __syncthreads();
+                    for (int kb0 = 0; kb0 < nops; kb0 += kThreads) {
+                        const int k = kb0 + tid;
+                        const bool has = k < nops && flags[k].left && flags[k].need;
+                        const unsigned long long m = __ballot(has);
+                        if (lane == 0) s_wave_cnt[wave] = __popcll(m);
+                        __syncthreads();
+                        int base = s_base;
+                        for (int w = 0; w < wave; ++w) base += s_wave_cnt[w];
+                        if (has) need_list[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)k;
+                        __syncthreads();
+                        if (tid == 0) {
+                            int n = s_base;
+                            for (int w = 0; w < kWaves; ++w) n += s_wave_cnt[w];
+                            s_base = n;
+                        }
+                        __syncthreads();
                     }
-                    for (int k = wave; k < nops; k += kWaves) {
-                        const OpFlags f = flags[k];
-                        if (!f.left || !f.need) continue;
-                        const uint32_t a1 = __builtin_amdgcn_readfirstlane(a12[k] & 0xFF);
-                        const uint32_t a2 = __builtin_amdgcn_readfirstlane(a12[k] >> 8);
-                        const double* r1 = p.D + (size_t)a1 * C;  // wave-uniform row bases
+                    const int nneed = s_base;
+                    // each of them looks for its cheapest free core (first minimum); four ops per wave step
+                    uint32_t fmask = 0;  // bit it: this lane's column it * 16 + l16 exists and is free
+#pragma unroll
+                    for (int it = 0; it < 16; ++it) {
+                        const int j = it * 16 + l16;
+                        if (j < nav && cfree[j]) fmask |= 1u << it;
+                    }
+                    for (int nb = wave * 4; nb < nneed; nb += kWaves * 4) {
+                        const int e = nb + rowi;
+                        const bool act = e < nneed;
+                        const int k = need_list[act ? e : nb];  // a row without an op of its own repeats the first
+                        const uint32_t a1 = a12[k] & 0xFF, a2 = a12[k] >> 8;
+                        const double* r1 = p.D + (size_t)a1 * C;
                         const double* r2 = p.D + (size_t)a2 * C;
                         // key = bits of the entry (non-negative doubles order like their bits), idx = column
                         // with "finite" in bit 16; a lane looks at its columns in ascending order, so "<"
-                        // keeps its first minimum and the wave minimum breaks ties by column
+                        // keeps its first minimum and the row minimum breaks ties by column
                         unsigned long long key = ~0ull;
                         uint32_t idx = 0x7FFFFFFFu;
 #pragma unroll
-                        for (int jb = 0; jb < 4; ++jb) {
-                            if (jb * kWave < nav) {  // uniform
-                                const double val = r1[coff[jb]] + r2[coff[jb]];
+                        for (int it = 0; it < 16; ++it) {
+                            if (it < nit) {  // uniform
+                                const uint32_t c = (cpk[it >> 2] >> (8 * (it & 3))) & 0xFFu;
+                                const double val = r1[c] + r2[c];
                                 const bool fin = dfinite || isfinite(val);
                                 const unsigned long long kk = dbits(fin ? val : kBig);
-                                if (((fmask >> jb) & 1u) && kk < key) {
+                                if (((fmask >> it) & 1u) && kk < key) {
                                     key = kk;
-                                    idx = (uint32_t)(jb * kWave + lane) | (fin ? 0x10000u : 0u);
+                                    idx = (uint32_t)(it * 16 + l16) | (fin ? 0x10000u : 0u);
                                 }
                             }
                         }
-                        lexmin_wave(key, idx);
-                        if (lane == 0) {
+                        lexmin_row(key, idx);
+                        if (act && l16 == 0) {
                             bid[k] = __longlong_as_double((long long)key);
                             target[k] = (int)(idx & 0xFFFFu);
                             flags[k] = OpFlags{1, 0, (uint8_t)((idx >> 16) & 1u), 0};
@@ -396,13 +432,19 @@ extern "C" int qp_gtrhqa_place(const QpCircuit* circ, const QpDTable* dt, const 
     p.off_a12 = take((size_t)2 * max_ops);
     p.off_flags = take((size_t)4 * max_ops);
     p.off_cores = take((size_t)2 * dt->C);
+    p.off_need = take((size_t)2 * max_ops);
     if (off > 160u * 1024u) return qp::fail(QP_EINVAL, "qp_gtrhqa_place: circuit too wide for the on-chip state (%u bytes)", off);
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gtrhqa_place), hipFuncAttributeMaxDynamicSharedMemorySize, (int)off));
     int dev = 0, cus = 256, per_cu = 1;
     if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k_gtrhqa_place), kThreads, off));
-    const unsigned grid = (unsigned)std::min<int64_t>(B, (int64_t)std::max(cus, 1) * std::max(per_cu, 1));
-    k_gtrhqa_place<<<grid, kThreads, off, stream>>>(p);
+    cus = std::max(cus, 1);
+    // few instances: give each one a whole 16-wave workgroup; many: small workgroups, more of them per CU
+    const bool wide = B <= (int64_t)2 * cus;
+    void (*kern)(GpArgs) = wide ? k_gtrhqa_place<1024> : k_gtrhqa_place<256>;
+    const int threads = wide ? 1024 : 256;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)off));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), threads, off));
+    const unsigned grid = (unsigned)std::min<int64_t>(B, (int64_t)cus * std::max(per_cu, 1));
+    kern<<<grid, threads, off, stream>>>(p);
     HIP_TRY(hipGetLastError());
     return QP_OK;
 }

@@ -257,3 +257,33 @@ def test_core_activity_and_comm_matrix_random(Q, T, C, B):
             continue
         assert status[b] == 0 and M[b].tolist() == want
         assert (M[b] == M[b].T).all()
+
+
+def test_gtrhqa_device_placement_large_batch():
+    """Large batches run on small workgroups, small batches on one 16-wave workgroup per instance: both
+    must give the oracle's rows."""
+    import torch
+    from oracle import placer_oracle as O
+    from quantum_simulator_amd import engine, layered_gate_arrays
+    from quantum_simulator_amd.timeslices import CircuitIR
+    dev = torch.device("cuda", 0)
+    Q, T, C, cap, B = 96, 25, 16, 8, 700
+    rng = np.random.default_rng(12)
+    q0, q1, _ = layered_gate_arrays(Q, T, 0.6, seed=5)
+    ir = CircuitIR.from_gate_tables(Q, q0, q1)
+    eu = list(range(C)) + [0, 3, 5]
+    ev = [(i + 1) % C for i in range(C)] + [8, 11, 13]
+    D = engine.apsp(C, eu, ev, rng.uniform(1, 3, size=len(eu)))
+    dc, dt, eng = engine.DeviceCircuit(ir, dev), engine.DistanceTable(D, dev), engine.Engine(dev)
+    slots = np.repeat(np.arange(C), cap)
+    pad = np.zeros((B, dc.ldq), np.uint8)
+    for b in range(B):
+        pad[b, :Q] = rng.permutation(slots)[:Q]
+    big = eng.gtrhqa_place(dc, dt, torch.from_numpy(pad).to(dev), cap).cpu().numpy()
+    small = np.concatenate([eng.gtrhqa_place(dc, dt, torch.from_numpy(pad[s:s + 100].copy()).to(dev), cap).cpu().numpy()
+                            for s in range(0, B, 100)])
+    assert big.tobytes() == small.tobytes()
+    Dl = D.tolist()
+    for b in (0, 1, 350, 699):
+        want = np.array(O.place_gtrhqa(ir.slices, ir.gate_q, ir.gate_mr, Q, C, cap, Dl, init=pad[b, :Q].tolist()), np.uint8)
+        assert (big[b, :, :Q] == want).all(), b
