@@ -383,6 +383,29 @@ class hqa_placer(_HqaFamily):
         super().__init__(device)
         self.name = "HQA"
 
+    def simulate_broken_links(self, circuit, multicore_arch, num_simulations=10, break_probability=0.1):
+        """HQA_placer.py:325-361: ``num_simulations`` times, give every link an infinite weight with
+        probability ``break_probability`` (one draw of the global ``random`` stream per link, in
+        ``G.edges`` order), place and cost the circuit on the damaged network, and return the list of
+        (set of broken links, cost).  The architecture gets its own network back afterwards.  Distances
+        through a broken link are infinite, as networkx makes them (the link stays traversable)."""
+        import random
+        intact = multicore_arch.network
+        links = list(intact.edges)
+        results = []
+        try:
+            for _ in range(num_simulations):
+                damaged = intact.copy()
+                broken = {link for link in links if random.random() < break_probability}
+                for a, b in broken:
+                    damaged[a][b]["weight"] = float("inf")
+                multicore_arch.network = damaged
+                partition = self.place_per_timeslice(circuit, multicore_arch)
+                results.append((broken, self.per_timeslice_cost(circuit, partition, multicore_arch)))
+        finally:
+            multicore_arch.network = intact
+        return results
+
 
 class trhqa_placer(_HqaFamily):
     _kind = QP_CM_TRHQA
