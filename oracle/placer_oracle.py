@@ -18,6 +18,7 @@ operations are done one at a time, in the reference's order, so results agree bi
 """
 import heapq
 import random as _random
+import math
 from math import inf, isfinite
 
 NONE = None
@@ -848,3 +849,44 @@ def qubo_decode(act, C, cap, x, Q):
             load[j] += 1
         part.append(row)
     return part
+
+
+def qubo_cpu_anneal(energy_of, N, sweeps, beta_hot, beta_cold, replicas, seed):
+    """TEST INFRASTRUCTURE: a plain sequential single-flip Metropolis annealer over N binary variables
+    with a geometric inverse-temperature schedule, the textbook form of what
+    neal.SimulatedAnnealingSampler().sample does at Qubo_placer.py:139-140.  ``energy_of(state)`` is the
+    objective; its pairwise coefficients are first read off by evaluating it on basis states (so nothing
+    here depends on any matrix the product builds).  Returns the best energy found over all replicas."""
+    import numpy as np
+    zero = np.zeros(N, np.int8)
+    e0 = energy_of(zero)
+    lin = np.zeros(N, np.int64)
+    for i in range(N):
+        s = zero.copy()
+        s[i] = 1
+        lin[i] = energy_of(s) - e0
+    W = np.zeros((N, N), np.int64)
+    for i in range(N):
+        for j in range(i + 1, N):
+            s = zero.copy()
+            s[i] = s[j] = 1
+            W[i, j] = W[j, i] = energy_of(s) - e0 - lin[i] - lin[j]
+    rng = np.random.default_rng(seed)
+    best = None
+    for _ in range(replicas):
+        s = rng.integers(0, 2, size=N).astype(np.int64)
+        field = W @ s
+        e = e0 + int(lin @ s) + int(s @ field) // 2
+        for k in range(sweeps):
+            beta = beta_hot * (beta_cold / beta_hot) ** (k / (sweeps - 1) if sweeps > 1 else 0.0)
+            u = rng.random(N)
+            for i in range(N):
+                d = 1 - 2 * int(s[i])
+                dE = d * (int(lin[i]) + int(field[i]))
+                if dE <= 0 or u[i] < math.exp(-beta * dE):
+                    s[i] += d
+                    field += d * W[:, i]
+                    e += dE
+        assert e == energy_of(s.astype(np.int8))
+        best = e if best is None else min(best, e)
+    return best

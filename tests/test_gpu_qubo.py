@@ -195,3 +195,35 @@ def test_qubo_placer_end_to_end(gpu):
     assert cost == O.cost_v4(gc.slices, gc.gate_q, gc.gate_mr, rows, gc.hops.tolist())
     again = qubo_placer(num_sweeps=400).place_per_timeslice(circ, arch)
     assert again == part
+
+
+def test_anneal_not_worse_than_plain_cpu_annealing(gpu):
+    """Same model, same number of sweeps, same temperature range: the best energy over the GPU's replicas
+    is at least as low as the best of a plain sequential CPU annealer (oracle.qubo_cpu_anneal, which reads
+    the coefficients off the restated objective, not off anything the product builds)."""
+    torch, dev = gpu
+    from quantum_simulator_amd.qubo import DeviceQubo
+    qm, names = _model(6, 3, 4, 3, 1)
+    act, inter = O.qubo_slices(qm.ir.slices, qm.ir.gate_q, names)
+    H = qm.H.tolist()
+    # position of every variable in the compact (unpadded) order x[t][j][i], then y[t][j][p]
+    index = []
+    for t in range(qm.T):
+        index += [qm.var_x(t, j, i) for j in range(qm.C) for i in range(qm.n[t])]
+        index += [qm.var_y(t, j, p) for j in range(qm.C) for p in range(qm.cap)]
+    N = len(index)
+
+    def energy_of(s):
+        st = np.zeros(qm.Npad, np.int8)
+        st[index] = s
+        x = [[[int(st[qm.var_x(t, j, i)]) for i in range(qm.n[t])] for j in range(qm.C)] for t in range(qm.T)]
+        y = [[[int(st[qm.var_y(t, j, p)]) for p in range(qm.cap)] for j in range(qm.C)] for t in range(qm.T)]
+        return O.qubo_energy(act, inter, qm.C, qm.cap, H, x, y)
+
+    sweeps = 200
+    hot, cold = qm.beta_range()
+    cpu_best = O.qubo_cpu_anneal(energy_of, N, sweeps, hot, cold, replicas=8, seed=3)
+    dq = DeviceQubo(qm, dev)
+    X, _ = dq.anneal(128, sweeps, seed=3)
+    gpu_best = int(dq.energy(X).min())
+    assert gpu_best <= cpu_best, (gpu_best, cpu_best)
