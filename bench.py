@@ -2,21 +2,25 @@
 """Headline benchmark: timeslice cost evaluations per second on MI355X.
 
 Workload (``config.workload``): the synthetic layered circuit with 1024 qubits x 1000 timeslices
-(256 two-qubit gates per slice) on a 16x16 mesh of cores, 4096 candidate partitions per GPU, costed
-with the HQA-family definition (the cost GTRHQA reports).  One step = one pass of the cost path over
-all partitions of the rank: qp_slice_cost_v3 through the C ABI, inputs resident in HBM.
+(256 two-qubit gates per slice) on a 16x16 mesh of cores, 4096 partitions per GPU, costed with the
+HQA-family definition (the cost GTRHQA reports).  By default the partitions are GTRHQA's own placements of
+the circuit, computed on the device from seeded shuffles of the block assignment (``--source walk`` uses a
+seeded random walk instead).  One step = one pass of the cost path over all partitions of the rank:
+qp_slice_cost_v3 through the C ABI, inputs resident in HBM.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--weights uniform|integer] [--partitions B]
-                    [--pmove P] [--no-cpu]
+                    [--source gtrhqa|walk] [--single] [--no-cpu] [--no-qubo]
 
 For N > 1 launch with torch.distributed.run (one rank per GPU); ranks work on disjoint partitions with
 no collective in the timed region; the final mean/min reduction over ranks (one RCCL all-reduce of a
 few doubles) is done once after it and reported as ``reduce_ms``.
 
-Rank 0 prints one JSON line.  ``roofline`` prices the dominant kernel (k_cost_v3) against HBM:
-algorithmic bytes per launch / mean launch time from HIP events on the launch stream.
-``cpu_baseline`` times the CPU oracle (a port of the reference's per_timeslice_cost loop) on a bounded
-sample of the same partitions on one host core.
+Rank 0 prints one JSON line.  ``roofline`` prices the dominant kernel of the headline variant against
+HBM: algorithmic bytes per launch / mean launch time from HIP events on the launch stream.
+``other_variants`` repeats the measurement with table look-ups forced and with non-integer weights
+(fp64 table); ``gtrhqa_place``, ``cost_matrix`` and ``qubo`` time the other device paths.
+``cpu_baseline`` times the CPU oracle (a C port of the reference's per_timeslice_cost loop) on a bounded
+sample of the same partitions on every host core, each result checked against the GPU's.
 """
 import argparse
 import json
