@@ -67,10 +67,16 @@ __global__ __launch_bounds__(kThreads) void k_comm_matrix(const uint8_t* A, cons
     int32_t* M = out + (size_t)b * C * C;
     const QpVisit v = visits[i];
     const uint32_t cur = base[(size_t)v.t * ldq + v.q];
-    bool bad = false;
+    // a core index outside the architecture (other than the "absent" mark) is reported like a missing
+    // qubit and never used as an index
+    bool bad = cur != QP_ABSENT && cur >= (uint32_t)C;
+    if (bad) {
+        status[b] = 1;
+        return;
+    }
     if (v.partner != 0xFFFFu) {
         const uint32_t oth = base[(size_t)v.t * ldq + v.partner];
-        if (cur == QP_ABSENT || oth == QP_ABSENT) {
+        if (cur == QP_ABSENT || oth == QP_ABSENT || oth >= (uint32_t)C) {
             bad = true;  // KeyError in the reference
         } else if (cur != oth) {
             atomicAdd(&M[cur * C + oth], 1);
@@ -80,7 +86,7 @@ __global__ __launch_bounds__(kThreads) void k_comm_matrix(const uint8_t* A, cons
     if (v.prev_t >= 0) {
         const uint32_t last = base[(size_t)v.prev_t * ldq + v.q];
         if (last != QP_ABSENT && cur != last) {
-            if (cur == QP_ABSENT) {
+            if (cur == QP_ABSENT || last >= (uint32_t)C) {
                 bad = true;  // list.index(None): ValueError in the reference
             } else {
                 atomicAdd(&M[cur * C + last], 1);

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(kThreads) void k_gtrhqa_place(GpArgs p) {
                 s_base = 0;
             }
             __syncthreads();
-            for (int q = tid; q < Q; q += kThreads) atomicAdd(&occ[a[q]], 1u);
+            for (int q = tid; q < Q; q += kThreads) atomicAdd(&occ[min((int)a[q], C - 1)], 1u);  // (a core id >= C is the caller's error; it must not index outside the table)
             __syncthreads();
 
             // columns: cores with room for a whole op, ascending (GTRHQA_placer.py:81-86)
@@ -176,8 +176,8 @@ __global__ __launch_bounds__(kThreads) void k_gtrhqa_place(GpArgs p) {
                     const QpEdge ed = p.edges[e];
                     u = ed.u;
                     v = ed.v;
-                    au = a[u];
-                    av = a[v];
+                    au = min((int)a[u], C - 1);
+                    av = min((int)a[v], C - 1);
                     has = au != av;
                 }
                 const unsigned long long m = __ballot(has);

@@ -159,6 +159,12 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3(V3Args p) {
     }
     const int ldq = p.ldq, G = p.G, lpr = p.lpr;
     const uint32_t C = (uint32_t)p.C;
+    // a table in device memory is never read past its end, whatever core ids the caller put in A (ids >= C
+    // are the caller's error; LDS tables need no guard: out-of-range LDS reads return nothing harmful)
+    auto in_table = [&](uint32_t idx) -> uint32_t {
+        if constexpr (TABMODE == kTabGlobal) return min(idx, C * C - 1u);
+        else return idx;
+    };
     uint8_t* strip = smem + tab_off + (size_t)wave * (G + 1) * ldq;  // [row before][G rows]
     const int nact = G * lpr;
     const bool lane_on = lane < nact;
@@ -176,7 +182,7 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3(V3Args p) {
     // distance of one (from, to) pair
     auto pair_at = [&](uint32_t from, uint32_t to) -> Acc {
         if constexpr (TABMODE == kTabLds256) return tab[(from << 8) | to];
-        else return tab[__umul24(from, C) + to];
+        else return tab[in_table(__umul24(from, C) + to)];
     };
     // sum over the four byte lanes of (from dword, to dword)
     auto four = [&](uint32_t pf, uint32_t cf) -> Acc {
@@ -187,7 +193,7 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3(V3Args p) {
         } else {
             Acc s = 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) s += (Acc)tab[__umul24((pf >> (8 * j)) & 0xFFu, C) + ((cf >> (8 * j)) & 0xFFu)];
+            for (int j = 0; j < 4; ++j) s += (Acc)tab[in_table(__umul24((pf >> (8 * j)) & 0xFFu, C) + ((cf >> (8 * j)) & 0xFFu))];
             return s;
         }
     };
@@ -311,6 +317,12 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_row(V3Args p) {
     }
     const int ldq = p.ldq;
     const uint32_t C = (uint32_t)p.C;
+    // a table in device memory is never read past its end, whatever core ids the caller put in A (ids >= C
+    // are the caller's error; LDS tables need no guard: out-of-range LDS reads return nothing harmful)
+    auto in_table = [&](uint32_t idx) -> uint32_t {
+        if constexpr (TABMODE == kTabGlobal) return min(idx, C * C - 1u);
+        else return idx;
+    };
     // Band mode: the band starts at a multiple of its (power of two) number of rows, so XOR-ing the
     // source core with band_lo maps the band onto 0..band_rows-1 and everything else above it; the byte
     // offset of (from ^ band_lo) << 8 | to is then clamped onto the zero entry that follows the band.
@@ -332,7 +344,7 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_row(V3Args p) {
     auto pair_at = [&](uint32_t from, uint32_t to) -> Acc {
         if constexpr (TABMODE == kTabLds256) return tab[(from << 8) | to];
         else if constexpr (TABMODE == kTabLdsBand) return band_at(((((from ^ (uint32_t)p.band_lo) << 8) | to)) * (uint32_t)sizeof(E));
-        else return tab[__umul24(from, C) + to];
+        else return tab[in_table(__umul24(from, C) + to)];
     };
     auto four = [&](uint32_t pf, uint32_t cf) -> Acc {
         if constexpr (TABMODE == kTabLds256) {
@@ -350,7 +362,7 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_row(V3Args p) {
         } else {
             Acc s = 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) s += (Acc)tab[__umul24((pf >> (8 * j)) & 0xFFu, C) + ((cf >> (8 * j)) & 0xFFu)];
+            for (int j = 0; j < 4; ++j) s += (Acc)tab[in_table(__umul24((pf >> (8 * j)) & 0xFFu, C) + ((cf >> (8 * j)) & 0xFFu))];
             return s;
         }
     };
@@ -618,6 +630,7 @@ __global__ __launch_bounds__(256) void k_cost_v3_wide(V3Args p) {
     using E = typename Tab<KIND>::elem;
     __shared__ double red[256 / kWave];
     const E* tab = static_cast<const E*>(p.table);
+    const uint32_t last = (uint32_t)p.C * (uint32_t)p.C - 1u;  // a core id >= C (caller's error) must not read past the table
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     for (int64_t it = blockIdx.x; it < p.nitems; it += gridDim.x) {
         const int chunk = (int)(it / p.B);
@@ -629,12 +642,12 @@ __global__ __launch_bounds__(256) void k_cost_v3_wide(V3Args p) {
         for (int row = max(r0, 2); row < r1; ++row) {
             const uint8_t* cr = base + (size_t)row * p.ldq;
             const uint8_t* pr = cr - p.ldq;
-            for (int q = threadIdx.x; q < p.Q; q += blockDim.x) acc += (double)tab[(uint32_t)pr[q] * p.C + cr[q]];
+            for (int q = threadIdx.x; q < p.Q; q += blockDim.x) acc += (double)tab[min((uint32_t)pr[q] * p.C + cr[q], last)];
         }
         for (int e = p.sep[r0] + threadIdx.x; e < p.sep[r1]; e += blockDim.x) {
             const QpEdge ed = p.edges[e];
             const uint8_t* cr = base + (size_t)ed.t * p.ldq;
-            acc += (double)tab[(uint32_t)cr[ed.u] * p.C + cr[ed.v]];
+            acc += (double)tab[min((uint32_t)cr[ed.u] * p.C + cr[ed.v], last)];
         }
         acc = wave_sum(acc);
         __syncthreads();
@@ -686,6 +699,7 @@ __global__ __launch_bounds__(256) void k_cost_v2(V2Args p) {
         tab = static_cast<const E*>(p.table);
     }
     const int C = p.C;
+    const uint32_t last = (uint32_t)C * (uint32_t)C - 1u;  // core ids >= C (caller's error) never index past the table
     for (int64_t it = (int64_t)blockIdx.x * nwaves + wave; it < p.nitems; it += (int64_t)gridDim.x * nwaves) {
         const int chunk = (int)(it / p.B);
         const int64_t b = it - (int64_t)chunk * p.B;
@@ -703,14 +717,14 @@ __global__ __launch_bounds__(256) void k_cost_v2(V2Args p) {
                 if (cur == QP_ABSENT || oth == QP_ABSENT) {
                     if (p.mode != QP_V1) bad = true;  // KeyError in the reference
                 } else {
-                    acc += (double)tab[cur * C + oth];
+                    acc += (double)tab[min(cur * C + oth, last)];
                 }
             }
             if (v.prev_t >= 0) {
-                const uint32_t last = base[(size_t)v.prev_t * p.ldq + v.q];
-                if (last != QP_ABSENT && cur != last) {
+                const uint32_t prev_core = base[(size_t)v.prev_t * p.ldq + v.q];
+                if (prev_core != QP_ABSENT && cur != prev_core) {
                     if (cur == QP_ABSENT) bad = true;  // distance to None: TypeError in the reference
-                    else acc += (double)(p.mode == QP_V4 ? tab[cur * C + last] : tab[last * C + cur]);
+                    else acc += (double)(p.mode == QP_V4 ? tab[min(cur * C + prev_core, last)] : tab[min(prev_core * C + cur, last)]);
                 }
             }
         }
@@ -787,7 +801,7 @@ __global__ __launch_bounds__(256) void k_cost_matrix(CmArgs p) {
             int q;
             if (k < 6) q = KINDC == QP_CM_GTRHQA ? -1 : p.lookahead[(size_t)eid * 6 + k];
             else q = k == 6 ? p.edges[eid].u : p.edges[eid].v;
-            if (q >= 0) v = a[q];
+            if (q >= 0) v = min((int)a[q], C - 1);  // a core id >= C is the caller's error; never index with it
         }
         opinfo[threadIdx.x >> 3][k] = v;
     }
@@ -807,7 +821,7 @@ __global__ __launch_bounds__(256) void k_cost_matrix(CmArgs p) {
     }
     __syncthreads();
     for (int j = threadIdx.x; j < n_av; j += blockDim.x) {
-        const int32_t c = p.avail[(size_t)b * C + j];
+        const int32_t c = min((int32_t)p.avail[(size_t)b * C + j], C - 1);
         const double* Dc = p.D + c;  // column c of the table
         double* outp = p.out + ((size_t)b * p.max_ops + i0) * C + j;
         // four ops at a time: their eight distance loads are issued before any of the arithmetic
