@@ -178,6 +178,30 @@ class BasePlacer:
     def place_per_timeslice(self, circuit, multicore_arch):
         raise NotImplementedError("Subclasses must implement place_per_timeslice method")
 
+    def simulate_broken_links(self, circuit, multicore_arch, num_simulations=10, break_probability=0.1):
+        """HQA_placer.py:325-361 == TRHQA_placer.py:628-669 == BFS_placer.py:241-278 == Random_placer.py:255-296:
+        ``num_simulations`` times, give every link an infinite weight with
+        probability ``break_probability`` (one draw of the global ``random`` stream per link, in
+        ``G.edges`` order), place and cost the circuit on the damaged network, and return the list of
+        (set of broken links, cost).  The architecture gets its own network back afterwards.  Distances
+        through a broken link are infinite, as networkx makes them (the link stays traversable)."""
+        import random
+        intact = multicore_arch.network
+        links = list(intact.edges)
+        results = []
+        try:
+            for _ in range(num_simulations):
+                damaged = intact.copy()
+                broken = {link for link in links if random.random() < break_probability}
+                for a, b in broken:
+                    damaged[a][b]["weight"] = float("inf")
+                multicore_arch.network = damaged
+                partition = self.place_per_timeslice(circuit, multicore_arch)
+                results.append((broken, self.per_timeslice_cost(circuit, partition, multicore_arch)))
+        finally:
+            multicore_arch.network = intact
+        return results
+
     def get_qpu_capacity(self, qpu_node, multicore_arch):
         return multicore_arch.network.nodes[qpu_node]["qpu"].available_qubits
 
@@ -383,29 +407,6 @@ class hqa_placer(_HqaFamily):
         super().__init__(device)
         self.name = "HQA"
 
-    def simulate_broken_links(self, circuit, multicore_arch, num_simulations=10, break_probability=0.1):
-        """HQA_placer.py:325-361: ``num_simulations`` times, give every link an infinite weight with
-        probability ``break_probability`` (one draw of the global ``random`` stream per link, in
-        ``G.edges`` order), place and cost the circuit on the damaged network, and return the list of
-        (set of broken links, cost).  The architecture gets its own network back afterwards.  Distances
-        through a broken link are infinite, as networkx makes them (the link stays traversable)."""
-        import random
-        intact = multicore_arch.network
-        links = list(intact.edges)
-        results = []
-        try:
-            for _ in range(num_simulations):
-                damaged = intact.copy()
-                broken = {link for link in links if random.random() < break_probability}
-                for a, b in broken:
-                    damaged[a][b]["weight"] = float("inf")
-                multicore_arch.network = damaged
-                partition = self.place_per_timeslice(circuit, multicore_arch)
-                results.append((broken, self.per_timeslice_cost(circuit, partition, multicore_arch)))
-        finally:
-            multicore_arch.network = intact
-        return results
-
 
 class trhqa_placer(_HqaFamily):
     _kind = QP_CM_TRHQA
@@ -477,6 +478,11 @@ class random_placer(_SparsePlacer):
     def __init__(self, device=None):
         super().__init__(device)
         self.name = "RANDOM"
+
+    def simulate_broken_links(self, circuit, multicore_arch, num_simulations=10, break_probability=0.1):
+        """Random_placer.py:255-296 places with ``place_per_timeslice_weighted_aware`` (:61-142), an alternate
+        placement that no configuration reaches and that this package does not provide."""
+        raise NotImplementedError("random_placer.simulate_broken_links needs place_per_timeslice_weighted_aware")
 
     def place_per_timeslice(self, circuit, multicore_arch):
         """Random_placer.py:25-59: per slice, every active qubit (in ``list(set(...))`` order) draws

@@ -337,9 +337,10 @@ def test_gtrhqa_full_size_invariants():
     assert (r[0, :7] == np.array(want, np.uint8)).all()
 
 
-@pytest.mark.parametrize("name", ["qft18_mesh4x4_u", "shor5_mesh2x2_i", "qft29_torus8x8_u"])
-def test_simulate_broken_links_matches_reference_fixture(name):
-    """hqa_placer.simulate_broken_links under the same seed as the unmodified reference
+@pytest.mark.parametrize("key", ["qft18_mesh4x4_u/HQA", "shor5_mesh2x2_i/HQA", "qft29_torus8x8_u/HQA",
+                                 "qft18_mesh4x4_u/TRHQA", "bigadder_mesh4x4_u/BFS"])
+def test_simulate_broken_links_matches_reference_fixture(key):
+    """simulate_broken_links under the same seed as the unmodified reference
     (tests/golden/broken_links.json): same links broken in every simulation, same cost (infinite where
     the damaged network forces a move across a broken link)."""
     import json
@@ -347,13 +348,14 @@ def test_simulate_broken_links_matches_reference_fixture(name):
     import random
     from conftest import ROOT
     from quantum_simulator_amd.placers import PLACERS
-    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "broken_links.json")))[name]
+    name, pname = key.split("/")
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "broken_links.json")))[key]
     gc = load_case(name)
     circ, arch = case_circuit(gc), case_arch(gc)
     before = arch.network
     eidx = {e: i for i, e in enumerate(arch.network.edges)}
     random.seed(gold["seed"])
-    got = PLACERS["HQA"]().simulate_broken_links(circ, arch, num_simulations=gold["num_simulations"],
+    got = PLACERS[pname]().simulate_broken_links(circ, arch, num_simulations=gold["num_simulations"],
                                                  break_probability=gold["break_probability"])
     assert arch.network is before
     assert len(got) == len(gold["sims"])
