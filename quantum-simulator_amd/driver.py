@@ -3,7 +3,9 @@ package's placers, with the work optionally sharded over the ranks of a torch.di
 
 Config format and required keys are the reference's (config_parser.py:20-84): ``key = value`` lines,
 ``#`` comments; keys mode, topology, num_cores_x, num_cores_y, ncm_qubits, ncp_qubits,
-edge_weight_range, circuit_folders, placers, repeats, out_csv, plot_file.  Optional additions:
+edge_weight_range, circuit_folders, placers, repeats, out_csv, plot_file.  Optional additions
+(``batch_repeats = 0`` runs every repeat on its own as main.py does; by default the repeats of HQA, TRHQA
+and GTRHQA, which draw no random numbers, run as one device batch):
 ``seed`` (seeds Python's global ``random`` once before the architecture is built; the reference never
 seeds, so its runs are not reproducible) and ``device``.
 
@@ -153,19 +155,40 @@ def run_simulation(cfg, device=None, verbose=True):
     # [cost sum, cost count, time sum, time count] per (file, placer)
     sums = np.zeros((len(files), len(names), 4))
     mins = np.full((len(files), len(names)), np.inf)
+    def record(fi, pi, dt, cost):
+        if math.isfinite(cost):
+            sums[fi, pi, 0] += cost
+            sums[fi, pi, 1] += 1
+            mins[fi, pi] = min(mins[fi, pi], cost)
+        if math.isfinite(dt):
+            sums[fi, pi, 2] += dt
+            sums[fi, pi, 3] += 1
+
+    batched = str(cfg.get("batch_repeats", "1")).strip().lower() not in ("0", "false", "no")
     unit = 0
     for fi, path in enumerate(files):
         circuit = None
         for pi, name in enumerate(names):
             if name not in placers:
                 continue
-            for rep in range(repeats):
-                mine = unit % world == rank
-                unit += 1
-                if not mine:
+            mine = [rep for rep in range(repeats) if (unit + rep) % world == rank]
+            unit += repeats
+            if not mine:
+                continue
+            if circuit is None:
+                circuit = circuit_from_qasm(path, maxwidth=1024)
+            # placers whose repeats do not depend on the random stream run them as one device batch
+            run_batch = getattr(placers[name], "run_repeats", None) if batched else None
+            if run_batch is not None:
+                try:
+                    times, costs = run_batch(circuit, arch, len(mine))
+                    for dt, cost in zip(times, costs):
+                        record(fi, pi, dt, cost)
                     continue
-                if circuit is None:
-                    circuit = circuit_from_qasm(path, maxwidth=1024)
+                except Exception as exc:  # noqa: BLE001 - fall back to one repeat at a time
+                    if verbose:
+                        print(f"[{name}] batched run failed ({exc}); repeating one at a time")
+            for rep in mine:
                 if world > 1 and name in ("RANDOM", "BFS"):
                     random.seed(zlib.crc32(f"{seed}|{path}|{name}|{rep}".encode()))
                 try:
@@ -177,13 +200,7 @@ def run_simulation(cfg, device=None, verbose=True):
                     if verbose:
                         print(f"[{name}] run failed: {exc}")
                     dt, cost = math.inf, math.inf
-                if math.isfinite(cost):
-                    sums[fi, pi, 0] += cost
-                    sums[fi, pi, 1] += 1
-                    mins[fi, pi] = min(mins[fi, pi], cost)
-                if math.isfinite(dt):
-                    sums[fi, pi, 2] += dt
-                    sums[fi, pi, 3] += 1
+                record(fi, pi, dt, cost)
     sums, mins = reduce_table(sums, mins, device)
 
     results = []

@@ -223,6 +223,24 @@ class _HqaFamily(BasePlacer):
         arr = ctx.partition_array(partition, dense=True, rows=T)
         return ctx.cost(arr, "v3")
 
+    def run_repeats(self, circuit, multicore_arch, n):
+        """``n`` repeats of (place, cost) as main.py:88-92 runs them, as one batch: the placements advance
+        together (place_batch) and one qp_slice_cost_v3 launch costs them all.  Returns (seconds per
+        placement, costs): two lists of length n."""
+        import time
+        import torch
+        ctx = self._context(circuit, multicore_arch)
+        t0 = time.perf_counter()
+        rows = self.place_batch(circuit, multicore_arch, B=n)
+        if not torch.is_tensor(rows):
+            pad = np.zeros(rows.shape[:2] + (ctx.dc.ldq,), np.uint8)
+            pad[:, :, :ctx.ir.Q] = rows
+            rows = torch.from_numpy(pad).to(ctx.device)
+        torch.cuda.synchronize(ctx.device)
+        dt = (time.perf_counter() - t0) / n
+        costs = ctx.eng.cost_v3(ctx.dc, ctx.arch.table, rows).cpu().numpy()
+        return [dt] * n, [float(c) for c in costs]
+
     def per_core_intercore_activity(self, circuit, partition, multicore_arch):
         """HQA_placer.py:288-321 (== TRHQA_placer.py:586-619): {core node: number of inter-core events it
         takes part in}, counted on the device."""
@@ -450,6 +468,18 @@ class gtrhqa_placer(_HqaFamily):
         if as_tensor:
             return rows
         return rows.cpu().numpy()[:, :, :Q]
+
+    def run_repeats(self, circuit, multicore_arch, n):
+        """As for the other HQA-family placers, with the rows never leaving the device."""
+        import time
+        import torch
+        ctx = self._context(circuit, multicore_arch)
+        t0 = time.perf_counter()
+        rows = self.place_batch(circuit, multicore_arch, B=n, as_tensor=True)
+        torch.cuda.synchronize(ctx.device)
+        dt = (time.perf_counter() - t0) / n
+        costs = ctx.eng.cost_v3(ctx.dc, ctx.arch.table, rows).cpu().numpy()
+        return [dt] * n, [float(c) for c in costs]
 
     def place_batch(self, circuit, multicore_arch, initial=None, B=None, threads=8, as_tensor=False):
         """B placements in one launch.  Returns uint8 [B, T+1, Q] (the reference's T+1 rows), or with

@@ -115,6 +115,12 @@ def test_example_config_end_to_end(tmp_path):
     assert round(res["HQA_cost_mean"] / w) == 386 and round(res["TRHQA_cost_mean"] / w) == 386
     header = (tmp_path / "out.csv").read_text().splitlines()[0]
     assert header == "file," + ",".join(f"{p}_time_mean,{p}_cost_mean" for p in gold["placers"])
+    # the repeats of the placers that draw no random numbers ran as one device batch; one repeat at a time
+    # (as main.py does) gives the same costs
+    cfg2 = dict(cfg, batch_repeats=0)
+    res2 = driver.run_simulation(cfg2, verbose=False)[0]
+    for p in ("HQA", "TRHQA", "GTRHQA"):
+        assert res2[f"{p}_cost_mean"] == res[f"{p}_cost_mean"], p
 
 
 @pytest.mark.parametrize("name", ["qft18_mesh4x4_u", "bigadder_mesh4x4_i", "qft18_mesh4x4_cap4_u", "shor5_star4_u"])
