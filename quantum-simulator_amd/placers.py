@@ -357,19 +357,16 @@ class _HqaFamily(BasePlacer):
                 go = np.flatnonzero(live & has)
                 if go.size == 0:
                     continue
-                n_ops = rem[go].sum(1).astype(np.int32)
-                n_av = room[go].sum(1).astype(np.int32)
+                rem_go, room_go = rem[go], room[go]
+                n_ops = rem_go.sum(1).astype(np.int32)
+                n_av = room_go.sum(1).astype(np.int32)
                 max_ops = int(n_ops.max())
-                ops = np.zeros((go.size, max_ops), np.int32)
-                avail = np.zeros((go.size, C), np.uint8)
-                op_lists, av_lists = [], []
-                for k, b in enumerate(go):
-                    idx = np.flatnonzero(rem[b])
-                    av = np.flatnonzero(room[b])
-                    ops[k, :idx.size] = e0 + idx
-                    avail[k, :av.size] = av
-                    op_lists.append(idx)
-                    av_lists.append(av)
+                # left-packed lists per instance (stable sort keeps slice order / core order): the ops still to
+                # place as positions in the slice's gate list, the cores with room
+                op_pos = np.argsort(~rem_go, axis=1, kind="stable")[:, :max_ops]
+                av_pos = np.argsort(~room_go, axis=1, kind="stable")
+                ops = np.where(np.arange(max_ops)[None, :] < n_ops[:, None], e0 + op_pos, 0).astype(np.int32)
+                avail = np.where(np.arange(C)[None, :] < n_av[:, None], av_pos, 0).astype(np.uint8)
                 ab = np.zeros((go.size, ctx.dc.ldq), np.uint8)
                 ab[:, :Q] = a[go]
                 M = ctx.eng.cost_matrix(
@@ -377,21 +374,27 @@ class _HqaFamily(BasePlacer):
                     torch.from_numpy(ab).to(dev), torch.from_numpy(ops).to(dev), torch.from_numpy(n_ops).to(dev),
                     torch.from_numpy(avail).to(dev), torch.from_numpy(n_av).to(dev)).cpu().numpy()
                 rr, cc, status = E.lsap_batch(M, n_ops, n_av, threads)
-                for k, b in enumerate(go):
-                    if status[k] != 0:          # the reference swallows the solver's exception: slice ends
-                        spent[b] = budget[b]
-                        continue
-                    m = min(int(n_ops[k]), int(n_av[k]))
-                    for i, j in zip(rr[k, :m].tolist(), cc[k, :m].tolist()):
-                        if M[k, i, j] != np.inf:
-                            e = op_lists[k][i]
-                            u, v, core = int(eu[e]), int(ev[e]), int(av_lists[k][j])
-                            occ[b, a[b, u]] -= 1
-                            occ[b, a[b, v]] -= 1
-                            a[b, u] = core
-                            a[b, v] = core
-                            occ[b, core] += 2
-                            rem[b, e] = False
+                failed = status != 0            # the reference swallows the solver's exception: slice ends
+                spent[go[failed]] = budget[go[failed]]
+                # every (instance, assigned op) pair at once: inside an instance the ops touch different
+                # qubits and different cores, so the order of application is free
+                m = np.minimum(n_ops, n_av)
+                width = rr.shape[1]
+                kk, ii = np.nonzero((np.arange(width)[None, :] < m[:, None]) & ~failed[:, None])
+                ri, ci = rr[kk, ii], cc[kk, ii]
+                keep = M[kk, ri, ci] != np.inf
+                kk, ri, ci = kk[keep], ri[keep], ci[keep]
+                if kk.size:
+                    bb = go[kk]
+                    e = op_pos[kk, ri]
+                    u, v = eu[e], ev[e]
+                    core = av_pos[kk, ci]
+                    np.subtract.at(occ, (bb, a[bb, u]), 1)
+                    np.subtract.at(occ, (bb, a[bb, v]), 1)
+                    a[bb, u] = core
+                    a[bb, v] = core
+                    np.add.at(occ, (bb, core), 2)
+                    rem[bb, e] = False
             out[:, t] = a
         return out
 
