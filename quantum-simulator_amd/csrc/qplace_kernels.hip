@@ -45,6 +45,14 @@ __device__ inline double wave_sum(uint32_t x) {
     return (double)v;
 }
 
+// 16 bytes of a partition row.  Rows are read exactly once, so the load is marked non-temporal: it does
+// not displace the gate lists and tables that every wave re-reads from the caches.
+__device__ inline uint4 load_row16(const uint8_t* ptr) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ptr));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 // Copies the distance table into LDS (16 bytes per thread per step; the device buffer is padded to a
 // multiple of 16 bytes) and returns the padded size.
 __device__ inline uint32_t stage_table(uint8_t* smem, const void* table, uint32_t bytes) {
@@ -212,7 +220,7 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3(V3Args p) {
             const int rg = r0 + g * G;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (g < ngroups && lane_on && rg + lrow < r1)
-                v = *reinterpret_cast<const uint4*>(base + (size_t)rg * ldq + lane * 16);
+                v = load_row16(base + (size_t)rg * ldq + lane * 16);
             return v;
         };
 
@@ -382,7 +390,7 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_row(V3Args p) {
         const uint32_t* sched_lane = p.edges_sched + lane;
         auto fetch_row = [&](int row) -> uint4 {
             const uint8_t* rp = base + (size_t)min(row, r1 - 1) * ldq;
-            return *reinterpret_cast<const uint4*>(rp + lane16);
+            return load_row16(rp + lane16);
         };
         // gate `lane` of chunk c of the row (a later slice's gates or padding if the row has fewer
         // chunks: the consumer skips those, so nothing here waits on a loaded value)
@@ -509,7 +517,7 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_grid_row(V3Args p) {
 
         auto fetch_row = [&](int row) -> uint4 {
             const uint8_t* rp = base + (size_t)min(row, r1 - 1) * ldq;  // wave-uniform
-            return *reinterpret_cast<const uint4*>(rp + lane16);
+            return load_row16(rp + lane16);
         };
         auto fetch_gate = [&](int row, int c) -> uint32_t {
             const uint32_t* gp = sched_lane + p.sptr[min(row, r1 - 1)];  // wave-uniform + lane
