@@ -367,8 +367,10 @@ __global__ __launch_bounds__(kThreads) void k_gtrhqa_place(GpArgs p) {
             }
             __syncthreads();
             uint8_t* orow = outb + (size_t)(t + 1) * ldq;
-            for (int k = tid * 16; k < ldq; k += kThreads * 16)
-                *reinterpret_cast<uint4*>(orow + k) = *reinterpret_cast<const uint4*>(a + k);
+            for (int k = tid * 16; k < ldq; k += kThreads * 16) {  // written once: keep it out of the caches
+                typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(a + k), reinterpret_cast<u32x4*>(orow + k));
+            }
             __syncthreads();
         }
     }

@@ -876,7 +876,7 @@ __global__ __launch_bounds__(256) void k_cost_matrix(CmArgs p) {
                     r = pymax(0.1, here - attraction);
                 }
             }
-            outp[(size_t)i * C] = r;
+            __builtin_nontemporal_store(r, &outp[(size_t)i * C]);  // written once, read by the host or a later kernel
             }
         }
     }
