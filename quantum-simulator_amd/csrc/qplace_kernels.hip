@@ -452,9 +452,20 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_row(V3Args p) {
                 }
                 const uint32_t c0 = cur.x & keep[0], c1 = cur.y & keep[1], c2 = cur.z & keep[2], c3 = cur.w & keep[3];
                 if (row >= 2) {  // movement is charged from row 2 on
-                    const bool moved = ((c0 ^ p0) | (c1 ^ p1) | (c2 ^ p2) | (c3 ^ p3)) != 0;
-                    if (__builtin_amdgcn_ballot_w64(moved) != 0)
-                        acc += (four(p0, c0) + four(p1, c1)) + (four(p2, c2) + four(p3, c3));
+                    if constexpr (TABMODE == kTabLdsBand) {
+                        // instruction-bound: skip only when no lane of the wave saw a qubit move
+                        const bool moved = ((c0 ^ p0) | (c1 ^ p1) | (c2 ^ p2) | (c3 ^ p3)) != 0;
+                        if (__builtin_amdgcn_ballot_w64(moved) != 0)
+                            acc += (four(p0, c0) + four(p1, c1)) + (four(p2, c2) + four(p3, c3));
+                    } else {
+                        // LDS-bound: a lane skips a group of four qubits that all stayed where they were; fewer
+                        // active lanes per look-up instruction means fewer bank conflicts (placers that move
+                        // few qubits per slice)
+                        if (c0 != p0) acc += four(p0, c0);
+                        if (c1 != p1) acc += four(p1, c1);
+                        if (c2 != p2) acc += four(p2, c2);
+                        if (c3 != p3) acc += four(p3, c3);
+                    }
                 }
                 {
                     Acc s = 0;

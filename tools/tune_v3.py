@@ -23,7 +23,7 @@ def main():
     q0, q1, _ = layered_gate_arrays(Q, T, 0.5, seed=2025)
     ir = CircuitIR.from_gate_tables(Q, q0, q1)
     dc, eng = DeviceCircuit(ir, dev), Engine(dev)
-    A = make_partitions(torch, dev, B, ir.T, Q, dc.ldq, 256, 8, 0.95, seed=777)
+    A = make_partitions(torch, dev, B, ir.T, Q, dc.ldq, 256, 8, float(os.environ.get("QP_PMOVE", "0.95")), seed=777)
     out = torch.empty(B, dtype=torch.float64, device=dev)
     random.seed(1234)
     weights = (2.0, 2.0) if len(sys.argv) < 2 or sys.argv[1] == "integer" else (1.0, 3.0)
