@@ -140,6 +140,21 @@ int qp_lsap_f64_batch(int32_t n, const int32_t* nr, const int32_t* nc, const dou
 int qp_timeslices(int32_t n_gates, const int32_t* gq0, const int32_t* gq1, int32_t Q, int32_t* order_out,
                   int32_t* slice_ptr_out, int32_t* T_out);
 
+/* OpenQASM 2.0 reader, the fast part: scans consecutive plain gate statements
+ *     name [ ( parameters ) ] reg[i] { , reg[j] } ;        (one to three arguments, each one qubit)
+ * from text[start..n), skipping white space and // comments, and stops in front of the first statement
+ * that is anything else (a declaration, include, gate definition, measure, reset, barrier, if, an
+ * argument naming a whole register or an unknown one, an index out of range): *stop_out is that
+ * statement's offset (n at the end of the text) and the caller handles it before scanning on.
+ * Quantum registers known so far: n_regs NUL-terminated names back to back in reg_names, their sizes,
+ * and the global index of their first qubit.  Per gate k < *n_out: name_hash[k] (FNV-1a of the name),
+ * name_pos[2k..] = offset, length of the name; param_pos[2k..] = offset, length of the text between the
+ * parentheses (-1, -1 without parameters); qidx[3k..] = global qubit indices, -1 for unused slots.
+ * Stands in for the per-statement work of pytket.qasm.circuit_from_qasm as main.py:80 uses it. */
+int qp_qasm_scan(const char* text, int64_t n, int64_t start, int32_t n_regs, const char* reg_names,
+                 const int32_t* reg_size, const int32_t* reg_base, int64_t cap, uint64_t* name_hash,
+                 int32_t* name_pos, int32_t* param_pos, int32_t* qidx, int64_t* n_out, int64_t* stop_out);
+
 /* Lays the counted gates of every slice out for QpCircuit.edges_sched / sched_ptr: words u | v << 16, each
  * slice padded with zero words (qubit 0 with itself: distance zero) to a multiple of QP_SCHED_CHUNK so that
  * a wave reads whole chunks without masking, QP_SCHED_TAIL zero words after the last slice so that reading

@@ -68,6 +68,9 @@ EXPORTS = {
                                     C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]),
     "qp_timeslices": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                 C.POINTER(C.c_int32)]),
+    "qp_qasm_scan": (C.c_int, [C.c_char_p, C.c_int64, C.c_int64, C.c_int32, C.c_char_p, C.c_void_p, C.c_void_p, C.c_int64,
+                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64),
+                               C.POINTER(C.c_int64)]),
     "qp_schedule_gates": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_int64]),
     "qp_dtable_pack": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.POINTER(C.c_int32),

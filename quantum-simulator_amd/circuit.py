@@ -113,25 +113,72 @@ class Command:
         return f"{self.op.name} {', '.join(map(str, self.qubits))}"
 
 
+class _GateRun:
+    """A run of plain gate statements kept as arrays (what the native scanner returns): name id per gate,
+    the distinct names and their kinds, parameter text spans, qubit indices in declaration order (-1 = unused
+    slot).  Command objects are only made when somebody iterates the circuit."""
+    __slots__ = ("text", "name_id", "names", "kinds", "param_pos", "qidx")
+
+    def __init__(self, text, name_id, names, kinds, param_pos, qidx):
+        self.text, self.name_id, self.names, self.kinds = text, name_id, names, kinds
+        self.param_pos, self.qidx = param_pos, qidx
+
+    def __len__(self):
+        return len(self.name_id)
+
+    def commands(self, qubit_of):
+        ops_plain = [Op(k, n, "") for n, k in zip(self.names, self.kinds)]
+        out = []
+        text = self.text
+        for nid, (pb, pl), qs in zip(self.name_id.tolist(), self.param_pos.tolist(), self.qidx.tolist()):
+            op = ops_plain[nid] if pb < 0 else Op(self.kinds[nid], self.names[nid], text[pb:pb + pl])
+            out.append(Command(op, [qubit_of[q] for q in qs if q >= 0]))
+        return out
+
+
 class Circuit:
     """Ordered list of commands over named qubit registers."""
 
     def __init__(self):
-        self._commands: List[Command] = []
+        self._items = []          # Command objects and _GateRun blocks, in program order
+        self._count = 0
+        self._flat = None         # all commands as objects, made on first iteration
         self._qregs: List[Tuple[str, int]] = []
         self._qubit_objs = {}
+        self._decl_order = []     # qubit objects in declaration order (what _GateRun indices refer to)
 
     def add_q_register(self, name: str, size: int):
         self._qregs.append((name, int(size)))
         for i in range(int(size)):
-            self._qubit_objs[(name, i)] = Qubit(name, i)
+            q = Qubit(name, i)
+            self._qubit_objs[(name, i)] = q
+            self._decl_order.append(q)
 
     def qubit(self, reg: str, index: int) -> Qubit:
         return self._qubit_objs[(reg, index)]
 
     def add_command(self, name: str, qubits: Sequence[Qubit], params: str = "", optype=None, bits=()):
         t = optype if optype is not None else OpType.of(name)
-        self._commands.append(Command(Op(t, name, params), list(qubits), bits))
+        self._items.append(Command(Op(t, name, params), list(qubits), bits))
+        self._count += 1
+        self._flat = None
+
+    def add_run(self, run: "_GateRun"):
+        if len(run):
+            self._items.append(run)
+            self._count += len(run)
+            self._flat = None
+
+    def _commands_list(self) -> List[Command]:
+        if self._flat is None:
+            flat = []
+            for it in self._items:
+                if isinstance(it, _GateRun):
+                    flat.extend(it.commands(self._decl_order))
+                else:
+                    flat.append(it)
+            self._flat = flat
+        return self._flat
 
     @property
     def qubits(self) -> List[Qubit]:
@@ -143,23 +190,49 @@ class Circuit:
 
     @property
     def n_gates(self) -> int:
-        return len(self._commands)
+        return self._count
 
     def __iter__(self):
-        return iter(self._commands)
+        return iter(self._commands_list())
 
     def __len__(self):
-        return len(self._commands)
+        return self._count
 
     def get_commands(self):
-        return list(self._commands)
+        return list(self._commands_list())
+
+    def gate_tables(self):
+        """(qubit index table int32 [n_gates, k] in ``self.qubits`` order with -1 for unused slots, bool
+        [n_gates] "is Measure or Reset") without making command objects for array-backed runs."""
+        order = {q: i for i, q in enumerate(self.qubits)}
+        decl_to_sorted = np.array([order[q] for q in self._decl_order] + [-1], np.int32)  # [-1] maps -1 to -1
+        width = 1
+        for it in self._items:
+            width = max(width, it.qidx.shape[1] if isinstance(it, _GateRun) else len(it.qubits))
+        tabs, mrs = [], []
+        for it in self._items:
+            if isinstance(it, _GateRun):
+                q = decl_to_sorted[it.qidx]
+                if q.shape[1] < width:
+                    q = np.concatenate([q, np.full((len(q), width - q.shape[1]), -1, np.int32)], axis=1)
+                tabs.append(q)
+                kind_mr = np.array([k in (OpType.Measure, OpType.Reset) for k in it.kinds], bool)
+                mrs.append(kind_mr[it.name_id])
+            else:
+                row = np.full((1, width), -1, np.int32)
+                row[0, :len(it.qubits)] = [order[q] for q in it.qubits]
+                tabs.append(row)
+                mrs.append(np.array([it.op.type in (OpType.Measure, OpType.Reset)], bool))
+        if not tabs:
+            return np.zeros((0, width), np.int32), np.zeros(0, bool)
+        return np.concatenate(tabs), np.concatenate(mrs)
 
 
 # ----------------------------------------------------------------------------------------------
 # OpenQASM 2.0 reader
 # ----------------------------------------------------------------------------------------------
 
-_ARG_RE = re.compile(r"^([A-Za-z_][A-Za-z0-9_]*)(?:\[(\d+)\])?$")
+_ARG_RE = re.compile(r"^([A-Za-z_][A-Za-z0-9_]*)\s*(?:\[\s*(\d+)\s*\])?$")
 _GATE_RE = re.compile(r"^([A-Za-z_][A-Za-z0-9_]*)\s*(\((.*)\))?\s*(.*)$", re.S)
 
 
@@ -171,32 +244,91 @@ def _strip_comments(text: str) -> str:
     return re.sub(r"//[^\n]*", "", text)
 
 
-def _split_statements(text: str) -> Iterable[str]:
-    """Yield ';'-terminated statements; a ``gate ... { ... }`` definition is one statement."""
-    i, n = 0, len(text)
-    while i < n:
-        while i < n and text[i].isspace():
-            i += 1
+class _Statements:
+    """Cursor over the ';'-terminated statements of a program text: ``next(pos)`` returns (statement with
+    comments removed, position after it), or (None, len) at the end.  A ``gate ... { ... }`` definition
+    is one statement.  The position of the next comment is remembered so a file is scanned once."""
+
+    def __init__(self, text: str):
+        self.text = text
+        self._comment = -2  # position of the first "//" at or after the last query, -1: none left
+
+    def _next_comment(self, k: int) -> int:
+        if self._comment != -1 and self._comment < k:
+            self._comment = self.text.find("//", k)
+        return self._comment
+
+    def next(self, i: int):
+        text = self.text
+        n = len(text)
+        while True:
+            while i < n and text[i].isspace():
+                i += 1
+            if text.startswith("//", i):
+                j = text.find("\n", i)
+                i = n if j < 0 else j + 1
+                continue
+            break
         if i >= n:
-            return
+            return None, n
         if text.startswith("gate", i) and (i + 4 < n and text[i + 4].isspace()):
             j = text.find("}", i)
             if j < 0:
                 raise QasmError("unterminated gate definition")
-            yield text[i:j + 1]
-            i = j + 1
-            continue
-        j = text.find(";", i)
+            return _strip_comments(text[i:j + 1]), j + 1
+        k = i
+        while True:  # the terminating ';' is the first one that is not inside a comment
+            j = text.find(";", k)
+            c = self._next_comment(k)
+            if c >= 0 and (j < 0 or c < j):
+                e = text.find("\n", c)
+                if e < 0:
+                    j = -1
+                    break
+                k = e + 1
+                continue
+            break
         if j < 0:
-            rest = text[i:].strip()
+            rest = _strip_comments(text[i:]).strip()
             if rest:
                 raise QasmError(f"missing ';' after: {rest[:40]!r}")
-            return
-        yield text[i:j].strip()
-        i = j + 1
+            return None, n
+        return _strip_comments(text[i:j]).strip(), j + 1
 
 
-def circuit_from_qasm_str(text: str, maxwidth: int = 32) -> Circuit:
+def _scan_plain_gates(circ: "Circuit", text: str, data: bytes, pos: int, qregs) -> int:
+    """Hands the run of plain gate statements that starts at ``pos`` to the native scanner
+    (qp_qasm_scan), appends it to ``circ`` as arrays and returns where the scanner stopped."""
+    import ctypes as C
+
+    from . import _lib
+    L = _lib.lib()
+    names_blob = b"".join(name.encode() + b"\0" for name, _ in qregs)
+    sizes = np.array([sz for _, sz in qregs], np.int32)
+    base = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int32) if len(qregs) else np.zeros(0, np.int32)
+    n = len(data)
+    while True:
+        cap = max(1024, min(1 << 20, (n - pos) // 8 + 16))
+        h = np.empty(cap, np.uint64)
+        npos = np.empty((cap, 2), np.int32)
+        ppos = np.empty((cap, 2), np.int32)
+        qidx = np.empty((cap, 3), np.int32)
+        cnt, stop = C.c_int64(0), C.c_int64(0)
+        _lib.check(L.qp_qasm_scan(data, n, pos, len(qregs), names_blob, _lib.ptr(sizes) if len(qregs) else None,
+                                  _lib.ptr(base) if len(qregs) else None, cap, _lib.ptr(h), _lib.ptr(npos),
+                                  _lib.ptr(ppos), _lib.ptr(qidx), C.byref(cnt), C.byref(stop)))
+        k = cnt.value
+        if k:
+            uh, first, inv = np.unique(h[:k], return_index=True, return_inverse=True)
+            names = [text[npos[f, 0]:npos[f, 0] + npos[f, 1]] for f in first.tolist()]
+            kinds = [OpType.of(nm) if nm in _PYTKET_NAMES else OpType.CustomGate for nm in names]
+            circ.add_run(_GateRun(text, inv.astype(np.int32), names, kinds, ppos[:k].copy(), qidx[:k].copy()))
+        pos = stop.value
+        if k < cap:
+            return pos
+
+
+def circuit_from_qasm_str(text: str, maxwidth: int = 32, native: bool = True) -> Circuit:
     circ = Circuit()
     qreg_size = {}
     creg_size = {}
@@ -231,7 +363,18 @@ def circuit_from_qasm_str(text: str, maxwidth: int = 32) -> Circuit:
                 (qs if kind == "q" else bs).append(it)
             circ.add_command(name, qs, params, optype=optype, bits=bs)
 
-    for st in _split_statements(_strip_comments(text)):
+    # Plain gate statements (nearly all of a circuit file) go through the native scanner in runs; every
+    # other statement is handled here, one at a time, between two runs.
+    use_native = native and text.isascii()
+    data = text.encode() if use_native else b""
+    pos = 0
+    statements = _Statements(text)
+    while True:
+        if use_native:
+            pos = _scan_plain_gates(circ, text, data, pos, circ._qregs)
+        st, pos = statements.next(pos)
+        if st is None:
+            break
         if not st:
             continue
         head = st.split(None, 1)[0]

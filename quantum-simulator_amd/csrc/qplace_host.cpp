@@ -509,3 +509,145 @@ extern "C" int qp_schedule_gates(int32_t T, const int32_t* slice_edge_ptr, const
     }
     return QP_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// OpenQASM 2.0: runs of plain gate statements
+// ------------------------------------------------------------------------------------------------
+
+namespace {
+
+inline bool ident_start(char c) { return (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || c == '_'; }
+inline bool ident_char(char c) { return ident_start(c) || (c >= '0' && c <= '9'); }
+
+// skips white space and // comments
+inline int64_t skip_blank(const char* t, int64_t n, int64_t i) {
+    for (;;) {
+        while (i < n && (t[i] == ' ' || t[i] == '\t' || t[i] == '\n' || t[i] == '\r' || t[i] == '\f' || t[i] == '\v')) ++i;
+        if (i + 1 < n && t[i] == '/' && t[i + 1] == '/') {
+            while (i < n && t[i] != '\n') ++i;
+            continue;
+        }
+        return i;
+    }
+}
+
+inline bool is_keyword(const char* s, int64_t len) {
+    static const char* const kw[] = {"OPENQASM", "include", "qreg", "creg", "gate", "opaque", "measure", "reset", "barrier", "if"};
+    for (const char* k : kw)
+        if ((int64_t)std::strlen(k) == len && std::memcmp(k, s, (size_t)len) == 0) return true;
+    return false;
+}
+
+}  // namespace
+
+extern "C" int qp_qasm_scan(const char* text, int64_t n, int64_t start, int32_t n_regs, const char* reg_names,
+                            const int32_t* reg_size, const int32_t* reg_base, int64_t cap, uint64_t* name_hash,
+                            int32_t* name_pos, int32_t* param_pos, int32_t* qidx, int64_t* n_out, int64_t* stop_out) {
+    if (!text || n < 0 || start < 0 || start > n || cap < 0 || !n_out || !stop_out || n > 0x7FFFFFFF ||
+        (cap > 0 && (!name_hash || !name_pos || !param_pos || !qidx)) || (n_regs > 0 && (!reg_names || !reg_size || !reg_base)))
+        return qp::fail(QP_EINVAL, "qp_qasm_scan: bad argument");
+    std::vector<std::pair<const char*, size_t>> regs;
+    {
+        const char* r = reg_names;
+        for (int32_t k = 0; k < n_regs; ++k) {
+            const size_t len = std::strlen(r);
+            regs.emplace_back(r, len);
+            r += len + 1;
+        }
+    }
+    int64_t i = start, count = 0;
+    while (count < cap) {
+        const int64_t st = skip_blank(text, n, i);
+        int64_t j = st;
+        if (j >= n || !ident_start(text[j])) {
+            i = st;
+            break;
+        }
+        while (j < n && ident_char(text[j])) ++j;
+        const int64_t nb = st, nl = j - st;
+        if (is_keyword(text + nb, nl)) {
+            i = st;
+            break;
+        }
+        j = skip_blank(text, n, j);
+        int64_t pb = -1, pl = -1;
+        if (j < n && text[j] == '(') {
+            int depth = 0;
+            int64_t k = j;
+            for (; k < n; ++k) {
+                if (text[k] == '(') ++depth;
+                else if (text[k] == ')' && --depth == 0) break;
+                else if (text[k] == ';') break;
+            }
+            if (k >= n || text[k] != ')') {
+                i = st;
+                break;
+            }
+            pb = j + 1;
+            pl = k - j - 1;
+            j = skip_blank(text, n, k + 1);
+        }
+        int32_t q[3] = {-1, -1, -1};
+        int nq = 0;
+        bool ok = true;
+        for (;;) {
+            if (j >= n || !ident_start(text[j]) || nq == 3) {
+                ok = false;
+                break;
+            }
+            int64_t k = j;
+            while (k < n && ident_char(text[k])) ++k;
+            int32_t reg = -1;
+            for (int32_t r = 0; r < n_regs; ++r)
+                if ((int64_t)regs[r].second == k - j && std::memcmp(regs[r].first, text + j, (size_t)(k - j)) == 0) reg = r;
+            k = skip_blank(text, n, k);
+            if (reg < 0 || k >= n || text[k] != '[') {
+                ok = false;
+                break;
+            }
+            k = skip_blank(text, n, k + 1);
+            int64_t v = 0, digits = 0;
+            while (k < n && text[k] >= '0' && text[k] <= '9' && digits < 9) {
+                v = v * 10 + (text[k] - '0');
+                ++k;
+                ++digits;
+            }
+            k = skip_blank(text, n, k);
+            if (digits == 0 || k >= n || text[k] != ']' || v >= reg_size[reg]) {
+                ok = false;
+                break;
+            }
+            q[nq++] = reg_base[reg] + (int32_t)v;
+            k = skip_blank(text, n, k + 1);
+            if (k < n && text[k] == ',') {
+                j = skip_blank(text, n, k + 1);
+                continue;
+            }
+            if (k < n && text[k] == ';') {
+                j = k + 1;
+                break;
+            }
+            ok = false;
+            break;
+        }
+        if (!ok || nq == 0) {
+            i = st;
+            break;
+        }
+        uint64_t h = 1469598103934665603ull;  // FNV-1a of the gate name
+        for (int64_t k = 0; k < nl; ++k) h = (h ^ (unsigned char)text[nb + k]) * 1099511628211ull;
+        name_hash[count] = h;
+        name_pos[2 * count] = (int32_t)nb;
+        name_pos[2 * count + 1] = (int32_t)nl;
+        param_pos[2 * count] = (int32_t)pb;
+        param_pos[2 * count + 1] = (int32_t)pl;
+        qidx[3 * count] = q[0];
+        qidx[3 * count + 1] = q[1];
+        qidx[3 * count + 2] = q[2];
+        ++count;
+        i = j;
+    }
+    *n_out = count;
+    *stop_out = i;
+    return QP_OK;
+}

@@ -74,10 +74,10 @@ def native_slices(Q: int, q0: np.ndarray, q1: np.ndarray):
 class CircuitIR:
     """Integer view of one circuit.  Build with ``CircuitIR.from_circuit`` or ``from_gate_tables``."""
 
-    def __init__(self, Q: int, gate_q, gate_mr, slices=None, qubits=None, commands=None, tables=None):
+    def __init__(self, Q: int, gate_q, gate_mr, slices=None, qubits=None, commands=None, tables=None, trusted=False):
         self.Q = int(Q)
-        self.gate_q = [tuple(int(x) for x in g) for g in gate_q]
-        self.gate_mr = [bool(x) for x in gate_mr]
+        self.gate_q = gate_q if trusted else [tuple(int(x) for x in g) for g in gate_q]
+        self.gate_mr = gate_mr if trusted else [bool(x) for x in gate_mr]
         n = len(self.gate_q)
         small = all(len(g) <= 2 for g in self.gate_q)
         if tables is not None:
@@ -91,7 +91,7 @@ class CircuitIR:
         self.slices = slices if slices is not None else slice_gate_indices(self.gate_q)
         self.T = len(self.slices)
         self.qubits = qubits          # circuit.qubits order (objects), or None
-        self.commands = commands      # command objects in file order, or None
+        self._commands = commands     # command objects in file order, a callable that makes them, or None
         if small:
             self._build_tables_vectorised(q0, q1)
         else:
@@ -178,6 +178,18 @@ class CircuitIR:
     @classmethod
     def from_circuit(cls, circuit) -> "CircuitIR":
         qubits = list(circuit.qubits)
+        tables = getattr(circuit, "gate_tables", None)
+        if tables is not None:
+            # this package's Circuit: integer tables straight from the reader, command objects only if
+            # somebody asks for them (break_into_timeslices)
+            tab, mr = tables()
+            nq = (tab >= 0).sum(1)
+            rows = tab.tolist()
+            gate_q = [tuple(r[:k]) for r, k in zip(rows, nq.tolist())]
+            small = tab.shape[1] <= 2 or not (nq > 2).any()
+            pair = (tab[:, 0].astype(np.int32), (tab[:, 1] if tab.shape[1] > 1 else np.full(len(tab), -1)).astype(np.int32))
+            return cls(len(qubits), gate_q, mr.tolist(), qubits=qubits, commands=circuit.get_commands,
+                       tables=pair if small and len(tab) else None, trusted=True)
         index = {q: i for i, q in enumerate(qubits)}
         commands = list(circuit)
         gate_q = [tuple(index[q] for q in c.qubits) for c in commands]
@@ -300,6 +312,12 @@ class CircuitIR:
     def active_qubits(self, t: int):
         a, b = int(self.slice_visit_ptr[t]), int(self.slice_visit_ptr[t + 1])
         return self.visit_records["q"][a:b]
+
+    @property
+    def commands(self):
+        if callable(self._commands):
+            self._commands = self._commands()
+        return self._commands
 
     def command_slices(self):
         """Timeslices as lists of command objects (the reference's return type)."""

@@ -263,3 +263,63 @@ def test_grid_metric_detection():
     for a in range(16):
         for b in range(16):
             assert want[a, b] == g.wx * abs(a % W - b % W) + g.wy * abs(a // W - b // W)
+
+
+TRICKY_QASM = '''OPENQASM 2.0; // header; with semicolon
+include "qelib1.inc";
+qreg q[3]; qreg r[2]; creg c[3];
+gate foo a,b { cx a,b; h a; }
+h q; // broadcast
+cx q[0],q[1]; rz(pi/2) q[2]; u3(0.1,(0.2),0.3) r[1];
+foo q[0], r[0];
+ccx q[0],q[1],q[2];
+barrier q;
+cx q[1], // split over lines; really
+   q[2];
+measure q -> c;
+if(c==3) x r[0];
+reset r[1];
+swap q [ 0 ] , r [ 1 ] ;
+'''
+
+
+def _commands(circ):
+    return [(x.op.name, x.op.params, [str(q) for q in x.qubits], x.op.type, x.bits) for x in circ]
+
+
+def test_native_qasm_reader_equals_python_reader():
+    """Runs of plain gate statements go through qp_qasm_scan; everything else (declarations, broadcasts,
+    user gates, measure, reset, barrier, conditionals, comments in odd places) through the Python reader.
+    Both routes must give the same commands in the same order, and the same integer tables."""
+    from quantum_simulator_amd import circuit_to_qasm_str, layered_circuit
+    from quantum_simulator_amd.circuit import QasmError, circuit_from_qasm_str
+    a, b = circuit_from_qasm_str(TRICKY_QASM), circuit_from_qasm_str(TRICKY_QASM, native=False)
+    assert _commands(a) == _commands(b) and len(a) == len(b) == 16
+    ia, ib = CircuitIR.from_circuit(a), CircuitIR.from_circuit(b)
+    assert ia.gate_q == ib.gate_q and ia.gate_mr == ib.gate_mr and ia.slices == ib.slices
+    assert [[c.op.name for c in sl] for sl in ia.command_slices()] == [[c.op.name for c in sl] for sl in ib.command_slices()]
+    text = circuit_to_qasm_str(layered_circuit(70, 40, 0.5, seed=3))
+    a, b = circuit_from_qasm_str(text), circuit_from_qasm_str(text, native=False)
+    assert _commands(a) == _commands(b)
+    ia, ib = CircuitIR.from_circuit(a), CircuitIR.from_circuit(b)
+    assert ia.gate_q == ib.gate_q and ia.slices == ib.slices and ia.edge_records.tobytes() == ib.edge_records.tobytes()
+    for bad in ("qreg q[2]; cx q[0],q[5];", "qreg q[2]; cx q[0] q[1];", "qreg q[2]; h p[0];", "qreg q[2]; h q[0]"):
+        for native in (True, False):
+            with pytest.raises(QasmError):
+                circuit_from_qasm_str(bad, native=native)
+
+
+def test_qasm_scan_stops_where_it_should():
+    text = b"h q[0]; cx q[0],q[1];\n// note\nrz(0.5*(pi)) q[1]; measure q[0] -> c[0]; x q[0];"
+    n = len(text)
+    sizes, base = np.array([2], np.int32), np.array([0], np.int32)
+    h = np.empty(8, np.uint64)
+    npos, ppos, qidx = np.empty((8, 2), np.int32), np.empty((8, 2), np.int32), np.empty((8, 3), np.int32)
+    cnt, stop = ctypes.c_int64(0), ctypes.c_int64(0)
+    _lib.check(_lib.lib().qp_qasm_scan(text, n, 0, 1, b"q\0", _lib.ptr(sizes), _lib.ptr(base), 8, _lib.ptr(h), _lib.ptr(npos),
+                                       _lib.ptr(ppos), _lib.ptr(qidx), ctypes.byref(cnt), ctypes.byref(stop)))
+    assert cnt.value == 3 and text[stop.value:].startswith(b"measure")
+    assert qidx[:3].tolist() == [[0, -1, -1], [0, 1, -1], [1, -1, -1]]
+    assert [text[a:a + l] for a, l in npos[:3].tolist()] == [b"h", b"cx", b"rz"]
+    assert ppos[0].tolist() == [-1, -1] and text[ppos[2, 0]:ppos[2, 0] + ppos[2, 1]] == b"0.5*(pi)"
+    assert h[0] != h[1]
