@@ -704,12 +704,18 @@ struct V2Args {
     uint32_t table_bytes;
 };
 
-template <int KIND, bool TAB_LDS>
-__global__ __launch_bounds__(256) void k_cost_v2(V2Args p) {
+constexpr int kV2Unroll = 2;  // visits per lane in flight
+constexpr int kV2Group = 4;   // partitions that share one pass over the visit records
+
+// One wave = (chunk of slices, kV2Group consecutive partitions).  The visit records are the same for every
+// partition, so each is loaded once and applied to the whole group; with kV2Unroll visits per lane that
+// puts 3 * kV2Unroll * kV2Group independent placement bytes in flight before the first table look-up.
+template <int KIND, bool TAB_LDS, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_cost_v2(V2Args p) {
     extern __shared__ __align__(16) uint8_t smem[];
     using E = typename Tab<KIND>::elem;
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    const int nwaves = blockDim.x / kWave;
+    constexpr int nwaves = THREADS / kWave;
     const E* tab;
     if constexpr (TAB_LDS) {
         stage_table(smem, p.table, p.table_bytes);
@@ -719,37 +725,78 @@ __global__ __launch_bounds__(256) void k_cost_v2(V2Args p) {
     }
     const int C = p.C;
     const uint32_t last = (uint32_t)C * (uint32_t)C - 1u;  // core ids >= C (caller's error) never index past the table
+    const int64_t ngroups = (p.B + kV2Group - 1) / kV2Group;
+    const size_t pstride = (size_t)p.Tp * p.ldq;
     for (int64_t it = (int64_t)blockIdx.x * nwaves + wave; it < p.nitems; it += (int64_t)gridDim.x * nwaves) {
-        const int chunk = (int)(it / p.B);
-        const int64_t b = it - (int64_t)chunk * p.B;
+        const int chunk = (int)(it / ngroups);
+        const int64_t b0 = (it - (int64_t)chunk * ngroups) * kV2Group;
         const int r0 = chunk * p.rows_per_item;
         const int r1 = min(p.T, r0 + p.rows_per_item);
-        const uint8_t* base = p.A + (size_t)b * p.Tp * p.ldq;
-        double acc = 0.0;
-        bool bad = false;
-        for (int i = p.svp[r0] + lane; i < p.svp[r1]; i += kWave) {
-            const QpVisit v = p.visits[i];
-            const uint8_t* rowp = base + (size_t)v.t * p.ldq;
-            const uint32_t cur = rowp[v.q];
-            if (v.partner != 0xFFFFu) {
-                const uint32_t oth = rowp[v.partner];
-                if (cur == QP_ABSENT || oth == QP_ABSENT) {
-                    if (p.mode != QP_V1) bad = true;  // KeyError in the reference
-                } else {
-                    acc += (double)tab[min(cur * C + oth, last)];
+        const uint8_t* base[kV2Group];  // a group that runs past B repeats the last partition and drops the copies
+#pragma unroll
+        for (int g = 0; g < kV2Group; ++g) base[g] = p.A + (size_t)min(b0 + g, p.B - 1) * pstride;
+        double acc[kV2Group];
+        bool bad[kV2Group];
+#pragma unroll
+        for (int g = 0; g < kV2Group; ++g) {
+            acc[g] = 0.0;
+            bad[g] = false;
+        }
+        const int vend = p.svp[r1];
+        for (int i0 = p.svp[r0]; i0 < vend; i0 += kV2Unroll * kWave) {
+            QpVisit v[kV2Unroll];
+#pragma unroll
+            for (int u = 0; u < kV2Unroll; ++u) {
+                const int i = i0 + u * kWave + lane;
+                if (i < vend) {
+                    v[u] = p.visits[i];
+                } else {  // reads the item's first row, which exists, and adds nothing
+                    v[u].q = 0;
+                    v[u].partner = 0xFFFFu;
+                    v[u].t = r0;
+                    v[u].prev_t = -1;
                 }
             }
-            if (v.prev_t >= 0) {
-                const uint32_t prev_core = base[(size_t)v.prev_t * p.ldq + v.q];
-                if (prev_core != QP_ABSENT && cur != prev_core) {
-                    if (cur == QP_ABSENT) bad = true;  // distance to None: TypeError in the reference
-                    else acc += (double)(p.mode == QP_V4 ? tab[min(cur * C + prev_core, last)] : tab[min(prev_core * C + cur, last)]);
+            uint32_t cur[kV2Unroll][kV2Group], oth[kV2Unroll][kV2Group], prv[kV2Unroll][kV2Group];
+#pragma unroll
+            for (int u = 0; u < kV2Unroll; ++u) {
+                const size_t row = (size_t)v[u].t * p.ldq;
+                const size_t o_cur = row + v[u].q;
+                const size_t o_oth = row + (v[u].partner != 0xFFFFu ? v[u].partner : v[u].q);
+                const size_t o_prv = (size_t)(v[u].prev_t >= 0 ? v[u].prev_t : v[u].t) * p.ldq + v[u].q;
+#pragma unroll
+                for (int g = 0; g < kV2Group; ++g) {
+                    cur[u][g] = base[g][o_cur];
+                    oth[u][g] = base[g][o_oth];
+                    prv[u][g] = base[g][o_prv];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kV2Unroll; ++u) {
+#pragma unroll
+                for (int g = 0; g < kV2Group; ++g) {
+                    const uint32_t c = cur[u][g], o = oth[u][g], q = prv[u][g];
+                    if (v[u].partner != 0xFFFFu) {
+                        if (c == QP_ABSENT || o == QP_ABSENT) {
+                            if (p.mode != QP_V1) bad[g] = true;  // KeyError in the reference
+                        } else {
+                            acc[g] += (double)tab[min(c * C + o, last)];
+                        }
+                    }
+                    if (v[u].prev_t >= 0 && q != QP_ABSENT && c != q) {
+                        if (c == QP_ABSENT) bad[g] = true;  // distance to None: TypeError in the reference
+                        else acc[g] += (double)(p.mode == QP_V4 ? tab[min(c * C + q, last)] : tab[min(q * C + c, last)]);
+                    }
                 }
             }
         }
-        acc = wave_sum(acc);
-        const bool any_bad = __builtin_amdgcn_ballot_w64(bad) != 0;
-        if (lane == 0) p.partial[it] = any_bad ? std::numeric_limits<double>::infinity() : acc;
+#pragma unroll
+        for (int g = 0; g < kV2Group; ++g) {
+            const double s = wave_sum(acc[g]);
+            const bool any_bad = __builtin_amdgcn_ballot_w64(bad[g]) != 0;
+            if (lane == 0 && b0 + g < p.B)
+                p.partial[(size_t)chunk * p.B + b0 + g] = any_bad ? std::numeric_limits<double>::infinity() : s;
+        }
     }
 }
 
@@ -1113,21 +1160,33 @@ extern "C" int qp_slice_cost_v2(const QpCircuit* circ, const QpDTable* dt, const
     p.mode = flags;
     p.rows_per_item = 32;
     const int32_t nchunks = (T + p.rows_per_item - 1) / p.rows_per_item;
-    p.nitems = (int64_t)nchunks * B;
-    if (!workspace || workspace_bytes < (size_t)p.nitems * sizeof(double))
-        return qp::fail(QP_ENOSPC, "qp_slice_cost_v2: workspace needs %zu bytes", (size_t)p.nitems * sizeof(double));
+    const size_t need = (size_t)nchunks * B * sizeof(double);
+    p.nitems = (int64_t)nchunks * ((B + kV2Group - 1) / kV2Group);
+    if (!workspace || workspace_bytes < need) return qp::fail(QP_ENOSPC, "qp_slice_cost_v2: workspace needs %zu bytes", need);
     p.partial = static_cast<double*>(workspace);
     const size_t esz = dt->kind == QP_DT_F64 ? 8 : 2;
     p.table_bytes = (uint32_t)((size_t)dt->C * dt->C * esz);
     const size_t tab_padded = (p.table_bytes + 15u) & ~(size_t)15;
-    const bool tab_lds = tab_padded <= 64 * 1024;
-    const size_t lds = tab_lds ? tab_padded : 0;
+    // A table of up to 64 KB shares the CU's LDS between several 256-thread workgroups; a larger one that
+    // still fits (every 16-bit table does: 255 cores are 127 KB) gets one 1024-thread workgroup per CU.
+    // Random look-ups in a table left in global memory touch one cache line per lane and bound the kernel.
+    const bool tab_small = tab_padded <= 64 * 1024;
+    const bool tab_big = !tab_small && tab_padded <= 144 * 1024;
+    const size_t lds = (tab_small || tab_big) ? tab_padded : 0;
+    const int threads = tab_big ? 1024 : 256;
     const int cus = device_cus();
-    const unsigned grid = (unsigned)std::min<int64_t>((int64_t)cus * 2, (p.nitems + 3) / 4);
     void (*kern)(V2Args) = nullptr;
-    if (dt->kind == QP_DT_F64) kern = tab_lds ? k_cost_v2<QP_DT_F64, true> : k_cost_v2<QP_DT_F64, false>;
-    else kern = tab_lds ? k_cost_v2<QP_DT_U16, true> : k_cost_v2<QP_DT_U16, false>;
-    kern<<<grid, 256, lds, stream>>>(p);
+    if (dt->kind == QP_DT_F64)
+        kern = tab_small ? k_cost_v2<QP_DT_F64, true, 256> : tab_big ? k_cost_v2<QP_DT_F64, true, 1024> : k_cost_v2<QP_DT_F64, false, 256>;
+    else
+        kern = tab_small ? k_cost_v2<QP_DT_U16, true, 256> : tab_big ? k_cost_v2<QP_DT_U16, true, 1024> : k_cost_v2<QP_DT_U16, false, 256>;
+    if (lds > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = 1;  // the loop hides gather latency with resident waves: as many workgroups as fit
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), threads, lds));
+    const int wpb = threads / kWave;
+    const unsigned grid = (unsigned)std::min<int64_t>((int64_t)cus * std::max(per_cu, 1), (p.nitems + wpb - 1) / wpb);
+    kern<<<grid, threads, lds, stream>>>(p);
     HIP_TRY(hipGetLastError());
     k_sum_chunks<<<(unsigned)((B + 255) / 256), 256, 0, stream>>>(p.partial, B, nchunks, out);
     HIP_TRY(hipGetLastError());
