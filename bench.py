@@ -256,6 +256,10 @@ def main():
             kname = "k_cost_v3_row<u16, grid>" if closed else "k_cost_v3_row<u16, lds256>"
         elif C * C * 8 <= 128 * 1024:
             how, kname = "f64, LDS-resident", "k_cost_v3_row<f64, lds>"
+        elif table == "packed" and dt.symmetric:
+            how = ("f64, 512 KB (too large for LDS), symmetric to rounding: core pairs are counted in LDS "
+                   "(uint32 per unordered pair), one product with the table per partition")
+            kname = "k_cost_v3_pairs"
         else:
             how, kname = "f64, 512 KB: LDS-resident in 4 bands of source cores, one pass per band", "k_cost_v3_row<f64, band> x4"
         for _ in range(args.warmup):

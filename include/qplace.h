@@ -100,6 +100,11 @@ typedef struct QpDTable {
     int32_t C;
     const void* table; /* dev, C*C entries, row-major, zero diagonal */
     QpGridMetric grid; /* all zero when unused; only consulted for QP_DT_U16 */
+    int32_t symmetric; /* QP_DT_F64 only: non-zero = qp_dtable_symmetric accepted the matrix.  The dense cost
+                          kernel may then use (D[a][b] + D[b][a]) / 2 for both directions of a pair, which is
+                          what lets a table of more than 134 cores work out of on-chip memory (pair counts
+                          instead of look-ups).  0 is always correct. */
+    int32_t reserved_;
 } QpDTable;
 
 int qp_version(void);
@@ -176,6 +181,12 @@ int qp_dtable_pack(const double* D_host, int32_t C, void* staging /* host */, si
 /* Tests whether a host distance matrix is a grid metric (see QpGridMetric); *out is zeroed when not. */
 int qp_dtable_grid_metric(const double* D_host, int32_t C, QpGridMetric* out);
 
+/* 1 if |D[a][b] - D[b][a]| <= rel_tol * max(|D[a][b]|, |D[b][a]|) for every pair (infinite entries must
+ * match exactly, NaN never passes), else 0; negative on bad arguments.  Distances over an undirected graph
+ * differ from their transposes only by the rounding of the sums along the path (Placer.py:63-76 accumulates
+ * from the source), a few units in the last place. */
+int qp_dtable_symmetric(const double* D_host, int32_t C, double rel_tol);
+
 /* ---------------------------------------------------------------- device: cost evaluation */
 
 /* Workspace (bytes, dev) qp_slice_cost_v3 / _v2 need for B partitions of circuit (T slices). */
@@ -187,7 +198,9 @@ size_t qp_slice_cost_workspace(int32_t T, int64_t B);
  * + sum over i = 2..T-1, all qubits q with A[i][q] != A[i-1][q]:                 D[A[i-1][q]][A[i][q]]
  * A: dev uint8 [B][Tp][ldq] (Tp >= T rows per partition, row pitch ldq >= Q, ldq % 16 == 0); row i is
  * used for slice i whatever Tp is (GTRHQA returns T+1 rows).  out: dev double [B].
- * Sums are formed in a fixed order (bitwise reproducible run to run); exact when D is QP_DT_U16. */
+ * Sums are formed in a fixed order (bitwise reproducible run to run); exact when D is QP_DT_U16.  With
+ * QP_DT_F64 and dt->symmetric set, a table too large for on-chip memory is applied as
+ * (D[a][b] + D[b][a]) / 2 to the number of times the unordered pair {a, b} occurs. */
 int qp_slice_cost_v3(const QpCircuit* circ, const QpDTable* dt, const uint8_t* A, int64_t B, int32_t Tp,
                      int32_t ldq, double* out, void* workspace, size_t workspace_bytes, void* stream);
 

@@ -30,7 +30,8 @@ class QpGridMetric(C.Structure):
 
 
 class QpDTable(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("C", C.c_int32), ("table", C.c_void_p), ("grid", QpGridMetric)]
+    _fields_ = [("kind", C.c_int32), ("C", C.c_int32), ("table", C.c_void_p), ("grid", QpGridMetric),
+                ("symmetric", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class QpQuboSeg(C.Structure):
@@ -76,6 +77,7 @@ EXPORTS = {
     "qp_dtable_pack": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.POINTER(C.c_int32),
                                  C.POINTER(C.c_size_t)]),
     "qp_dtable_grid_metric": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(QpGridMetric)]),
+    "qp_dtable_symmetric": (C.c_int, [C.c_void_p, C.c_int32, C.c_double]),
     "qp_slice_cost_workspace": (C.c_size_t, [C.c_int32, C.c_int64]),
     "qp_slice_cost_v3": (C.c_int, [C.POINTER(QpCircuit), C.POINTER(QpDTable), C.c_void_p, C.c_int64, C.c_int32,
                                    C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

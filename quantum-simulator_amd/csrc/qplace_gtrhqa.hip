@@ -10,12 +10,6 @@
 
 #include "qplace_internal.h"
 
-#define HIP_TRY(expr)                                                                          \
-    do {                                                                                       \
-        hipError_t e_ = (expr);                                                                \
-        if (e_ != hipSuccess) return qp::fail(QP_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
-    } while (0)
-
 namespace {
 
 constexpr int kWave = 64;
@@ -436,9 +430,8 @@ extern "C" int qp_gtrhqa_place(const QpCircuit* circ, const QpDTable* dt, const 
     p.off_cores = take((size_t)2 * dt->C);
     p.off_need = take((size_t)2 * max_ops);
     if (off > 160u * 1024u) return qp::fail(QP_EINVAL, "qp_gtrhqa_place: circuit too wide for the on-chip state (%u bytes)", off);
-    int dev = 0, cus = 256, per_cu = 1;
-    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    cus = std::max(cus, 1);
+    const int cus = qp::device_cus();
+    int per_cu = 1;
     // few instances: give each one a whole 16-wave workgroup; many: small workgroups, more of them per CU
     const bool wide = B <= (int64_t)2 * cus;
     void (*kern)(GpArgs) = wide ? k_gtrhqa_place<1024> : k_gtrhqa_place<256>;

@@ -328,6 +328,22 @@ extern "C" int qp_dtable_pack(const double* D, int32_t C, void* staging, size_t 
     return QP_OK;
 }
 
+extern "C" int qp_dtable_symmetric(const double* D, int32_t C, double rel_tol) {
+    if (!D || C <= 0 || !(rel_tol >= 0.0)) return qp::fail(QP_EINVAL, "qp_dtable_symmetric: bad arguments");
+    for (int32_t a = 0; a < C; ++a) {
+        for (int32_t b = a + 1; b < C; ++b) {
+            const double x = D[(size_t)a * C + b], y = D[(size_t)b * C + a];
+            if (std::isnan(x) || std::isnan(y)) return 0;
+            if (std::isinf(x) || std::isinf(y)) {
+                if (x != y) return 0;
+                continue;
+            }
+            if (std::fabs(x - y) > rel_tol * std::max(std::fabs(x), std::fabs(y))) return 0;
+        }
+    }
+    return 1;
+}
+
 extern "C" int qp_dtable_grid_metric(const double* D, int32_t C, QpGridMetric* out) {
     if (!D || !out || C <= 0 || C > 256) return qp::fail(QP_EINVAL, "qp_dtable_grid_metric: bad argument");
     *out = QpGridMetric{};

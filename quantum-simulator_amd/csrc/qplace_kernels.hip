@@ -9,12 +9,6 @@
 
 #include "qplace_internal.h"
 
-#define HIP_TRY(expr)                                                                          \
-    do {                                                                                       \
-        hipError_t e_ = (expr);                                                                \
-        if (e_ != hipSuccess) return qp::fail(QP_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
-    } while (0)
-
 namespace {
 
 constexpr int kWave = 64;
@@ -488,6 +482,200 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_row(V3Args p) {
     }
 }
 
+// fp64 table too large for LDS (more than about 134 cores), symmetric up to rounding: instead of looking
+// distances up, count how often every unordered pair of cores occurs and multiply by the table once per
+// item.  The counters (one uint32 per pair a < b, at b * (b - 1) / 2 + a: 127.5 KB for 256 cores) fit in
+// LDS where the table does not.  One workgroup = one item (rows r0..r1 of one partition); its waves take
+// consecutive runs of those rows, feed the shared counters with LDS atomics (only lanes whose pair has
+// two different cores issue one), and after a barrier the whole workgroup forms sum(count * Dsym) over
+// the table's triangle in a fixed order, zeroing the counters as it goes.  Dsym[a][b] is the mean of
+// D[a][b] and D[b][a] (written by k_sym_triangle), so what is lost against summing the directed entries
+// is |count(a->b) - count(b->a)| * |D[a][b] - D[b][a]| / 2 per pair.
+__global__ void k_sym_triangle(const double* D, int32_t C, double* tri) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = C * (C - 1) / 2;
+    if (k >= n) return;
+    int b = (int)((1.0 + sqrt(1.0 + 8.0 * (double)k)) * 0.5);  // largest b with b * (b - 1) / 2 <= k
+    while (b * (b - 1) / 2 > k) --b;
+    while ((b + 1) * b / 2 <= k) ++b;
+    const int a = k - b * (b - 1) / 2;
+    tri[k] = (D[(size_t)a * C + b] + D[(size_t)b * C + a]) * 0.5;
+}
+
+template <int AHEAD = kV3Ahead>
+__global__ __launch_bounds__(kV3Threads) void k_cost_v3_pairs(V3Args p) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int ldq = p.ldq;
+    // LDS: strips, the workgroup reduction, then the counters last, so that a pair index made from core
+    // ids >= C (the caller's error) lands past the allocation, where the hardware drops the access
+    uint8_t* strip = smem + (size_t)wave * ldq;
+    double* red = reinterpret_cast<double*>(smem + (size_t)kV3Waves * ldq);
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(red + kV3Waves);
+    const int ntri = p.C * (p.C - 1) / 2;
+    const double* tri = static_cast<const double*>(p.table);
+    for (int k = threadIdx.x; k < ntri; k += kV3Threads) cnt[k] = 0;
+    __syncthreads();
+
+    const bool lane_on = lane * 16 < ldq;
+    const int nvalid_row = min(16, max(0, p.Q - lane * 16));
+    uint32_t keep[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const int nb = min(4, max(0, nvalid_row - 4 * w));
+        keep[w] = nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u);
+    }
+    auto count = [&](uint32_t a, uint32_t b) {
+        if (a != b) {
+            const uint32_t hi = max(a, b), lo = min(a, b);
+            // byte offset 4 * (hi * (hi - 1) / 2 + lo), formed without the shift pair a division would cost
+            // an LDS-qualified pointer: the compiler then knows the update cannot touch the (global) slice
+            // pointers and keeps reading those through the scalar cache
+            typedef __attribute__((address_space(3))) uint8_t lds_u8;
+            typedef __attribute__((address_space(3))) uint32_t lds_u32;
+            lds_u32* slot = (lds_u32*)((lds_u8*)cnt + (__umul24(hi, hi - 1u) * 2u + lo * 4u));
+            __hip_atomic_fetch_add(slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
+    auto count4 = [&](uint32_t pf, uint32_t cf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) count((pf >> (8 * j)) & 0xFFu, (cf >> (8 * j)) & 0xFFu);
+    };
+
+    for (int64_t it = blockIdx.x; it < p.nitems; it += gridDim.x) {
+        const int chunk = (int)(it / p.B);
+        const int64_t b = it - (int64_t)chunk * p.B;
+        const int r0 = chunk * p.rows_per_item;
+        const int r1 = min(p.T, r0 + p.rows_per_item);
+        // runs that differ by at most one row: every wave reaches the barrier at about the same time
+        const int w0 = r0 + (r1 - r0) * wave / kV3Waves, w1 = r0 + (r1 - r0) * (wave + 1) / kV3Waves;
+        const uint8_t* base = p.A + (size_t)b * p.Tp * ldq;
+        if (w0 < w1) {
+            const int lane16 = lane_on ? lane * 16 : 0;
+            const uint32_t* sched_lane = p.edges_sched + lane;
+            auto fetch_row = [&](int row) -> uint4 { return load_row16(base + (size_t)min(row, w1 - 1) * ldq + lane16); };
+            // Slice starts in the gate list.  The barriers of this kernel keep the compiler from reading them
+            // through the scalar cache, and as wave-uniform vector loads it would move each result to a
+            // scalar register at once, draining every prefetch issued before it.  So they are loaded through
+            // an index the compiler cannot prove uniform, stay in vector registers, and are made scalar
+            // where they are used: the start of slice row + AHEAD + 1 is requested a row before it is
+            // needed, ahead of that row's other loads; start and end travel with the ring.
+            int opaque_zero = 0;
+            asm volatile("" : "+v"(opaque_zero));
+            auto slice_start = [&](int row) -> int { return p.sptr[min(row, w1) + opaque_zero]; };
+            auto fetch_gate = [&](int start, int c) -> uint32_t { return sched_lane[start + c * kWave]; };
+            uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+            if (w0 >= 1) {
+                const uint4 prv = fetch_row(w0 - 1);
+                p0 = prv.x & keep[0];
+                p1 = prv.y & keep[1];
+                p2 = prv.z & keep[2];
+                p3 = prv.w & keep[3];
+            }
+            uint4 ring[AHEAD];
+            uint32_t gring[AHEAD][kRowEdgeChunks];
+            int sring[AHEAD], ering[AHEAD];
+            int sp_next = slice_start(w0);
+#pragma unroll
+            for (int k = 0; k < AHEAD; ++k) {
+                sring[k] = sp_next;
+                sp_next = slice_start(w0 + k + 1);
+                ering[k] = sp_next;
+                ring[k] = fetch_row(w0 + k);
+                const int start = __builtin_amdgcn_readfirstlane(sring[k]);
+#pragma unroll
+                for (int c = 0; c < kRowEdgeChunks; ++c) gring[k][c] = fetch_gate(start, c);
+            }
+            // one row: consume slot k of the ring, refill it with row + AHEAD (REFILL), count the row's pairs
+            auto do_row = [&](int row, uint4& rslot, uint32_t (&gslot)[kRowEdgeChunks], int& sslot, int& eslot, bool refill) {
+                const uint4 cur = rslot;
+                const int s0 = __builtin_amdgcn_readfirstlane(sslot);
+                const int nch = (__builtin_amdgcn_readfirstlane(eslot) - s0) / kWave;
+                uint32_t gates[kRowEdgeChunks];
+#pragma unroll
+                for (int c = 0; c < kRowEdgeChunks; ++c) gates[c] = gslot[c];
+                if (refill) {
+                    const int sp_here = sp_next;             // start of slice row + AHEAD, asked for a row ago
+                    sp_next = slice_start(row + AHEAD + 1);  // used a row from now
+                    sslot = sp_here;
+                    eslot = sp_next;
+                    rslot = fetch_row(row + AHEAD);
+                    const int start = __builtin_amdgcn_readfirstlane(sp_here);
+#pragma unroll
+                    for (int c = 0; c < kRowEdgeChunks; ++c) gslot[c] = fetch_gate(start, c);
+                }
+                if (lane_on) *reinterpret_cast<uint4*>(strip + lane * 16) = cur;
+                uint32_t au[kRowEdgeChunks], av[kRowEdgeChunks];
+#pragma unroll
+                for (int c = 0; c < kRowEdgeChunks; ++c) {  // a chunk the row lacks: one qubit twice
+                    const uint32_t g = c < nch ? gates[c] : 0u;
+                    au[c] = strip[g & 0xFFFFu];
+                    av[c] = strip[g >> 16];
+                }
+                const uint32_t c0 = cur.x & keep[0], c1 = cur.y & keep[1], c2 = cur.z & keep[2], c3 = cur.w & keep[3];
+                if (row >= 2) {  // movement is charged from row 2 on
+                    if (c0 != p0) count4(p0, c0);
+                    if (c1 != p1) count4(p1, c1);
+                    if (c2 != p2) count4(p2, c2);
+                    if (c3 != p3) count4(p3, c3);
+                }
+#pragma unroll
+                for (int c = 0; c < kRowEdgeChunks; ++c) count(au[c], av[c]);
+                for (int c = kRowEdgeChunks; c < nch; ++c) {
+                    const uint32_t g = sched_lane[s0 + c * kWave];
+                    count(strip[g & 0xFFFFu], strip[g >> 16]);
+                }
+                p0 = c0;
+                p1 = c1;
+                p2 = c2;
+                p3 = c3;
+            };
+            // whole groups of AHEAD rows without an exit inside the group (the ring then stays in fixed
+            // registers), then the up to AHEAD - 1 rows that are left, already in the ring
+            int g0 = w0;
+            for (; g0 + AHEAD <= w1; g0 += AHEAD) {
+#pragma unroll
+                for (int k = 0; k < AHEAD; ++k) do_row(g0 + k, ring[k], gring[k], sring[k], ering[k], true);
+            }
+#pragma unroll
+            for (int k = 0; k < AHEAD - 1; ++k)
+                if (g0 + k < w1) do_row(g0 + k, ring[k], gring[k], sring[k], ering[k], false);
+        }
+        __syncthreads();
+        // table entries are loaded whether or not the pair occurred (coalesced, cache-resident), eight at a
+        // time, so the loop is not a chain of load latencies; an unused entry may be infinite: select, not multiply
+        double acc = 0.0;
+        for (int k0 = threadIdx.x; k0 < ntri; k0 += 8 * kV3Threads) {
+            double d[8];
+            uint32_t n[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = k0 + j * kV3Threads;
+                d[j] = tri[min(k, ntri - 1)];
+                n[j] = k < ntri ? cnt[k] : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (n[j]) {
+                    cnt[k0 + j * kV3Threads] = 0;
+                    acc += (double)n[j] * d[j];
+                }
+            }
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) red[wave] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double s = 0.0;
+            for (int w = 0; w < kV3Waves; ++w) s += red[w];
+            p.partial[it] = s;
+        }
+        // the next item's counting cannot pass the barrier after it before thread 0 has read red[]; its
+        // counter updates touch entries this pass has already zeroed or left at zero
+    }
+}
+
 // Rows longer than 512 bytes under a grid metric (no table).  Written for a low vector-instruction
 // count, which is what bounds it once nothing is looked up: row and gate loads use wave-uniform base
 // pointers plus a fixed per-lane offset; strips sit at a pitch of 1024 bytes; the previous row is
@@ -944,13 +1132,6 @@ __global__ __launch_bounds__(256) void k_cost_matrix(CmArgs p) {
 // launch helpers
 // ------------------------------------------------------------------------------------------------
 
-int device_cus() {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 256;
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 256;
-    return n;
-}
-
 int rows_per_item_for(int32_t T, int32_t G, int64_t B, int cus) {
     if (G == 1) {
         // one row per step: long items amortise the pipeline fill at an item's start (the first rows are
@@ -982,7 +1163,8 @@ extern "C" size_t qp_slice_cost_workspace(int32_t T, int64_t B) {
     if (T <= 0 || B <= 0) return 16;
     // one double per (chunk, partition); chunks are never shorter than 16 rows unless T is
     const int64_t max_chunks = (T + 15) / 16 + 1;
-    return (size_t)(max_chunks * B) * sizeof(double) * 4;  // up to four table-band passes
+    // up to four table-band passes; room for the symmetrised triangle of a 256-core table
+    return (size_t)(max_chunks * B) * sizeof(double) * 4 + 256 + 256 * 255 / 2 * sizeof(double) + 256;
 }
 
 extern "C" int qp_slice_cost_v3(const QpCircuit* circ, const QpDTable* dt, const uint8_t* A, int64_t B, int32_t Tp,
@@ -1023,7 +1205,7 @@ extern "C" int qp_slice_cost_v3(const QpCircuit* circ, const QpDTable* dt, const
         p.lpr = 0;
         p.G = 1;
     }
-    const int cus = device_cus();
+    const int cus = qp::device_cus();
     p.rows_per_item = rows_per_item_for(T, p.G, B, cus);
     const int32_t nchunks = (T + p.rows_per_item - 1) / p.rows_per_item;
     p.nitems = (int64_t)nchunks * B;
@@ -1074,6 +1256,33 @@ extern "C" int qp_slice_cost_v3(const QpCircuit* circ, const QpDTable* dt, const
             k_sum_chunks<<<(unsigned)((B + 255) / 256), 256, 0, stream>>>(p.partial, B, nchunks, out);
             HIP_TRY(hipGetLastError());
             return QP_OK;
+        }
+        if (rowpath && mode == kTabGlobal && dt->kind == QP_DT_F64 && dt->symmetric && dt->C >= 2) {
+            // fp64 table too big for LDS but symmetric up to rounding: count core pairs in LDS, one pass
+            const int ntri = dt->C * (dt->C - 1) / 2;
+            const size_t tri_bytes = ((size_t)ntri * sizeof(double) + 255) & ~(size_t)255;
+            const size_t pairs_lds = (size_t)kV3Waves * ldq + kV3Waves * sizeof(double) + (size_t)ntri * sizeof(uint32_t);
+            // whole workgroups take an item; rows in runs of at least 4 per wave, about 8 items per workgroup
+            V3Args q = p;
+            const int64_t want = ((int64_t)T * B + (int64_t)cus * 8 - 1) / ((int64_t)cus * 8);
+            q.rows_per_item = (int)std::min<int64_t>(T, std::max<int64_t>(4 * kV3Waves, (want + kV3Waves - 1) / kV3Waves * kV3Waves));
+            const int32_t pchunks = (T + q.rows_per_item - 1) / q.rows_per_item;
+            q.nitems = (int64_t)pchunks * B;
+            const size_t part_bytes = ((size_t)q.nitems * sizeof(double) + 255) & ~(size_t)255;
+            if (pairs_lds <= (size_t)kLdsBytes && workspace_bytes >= part_bytes + tri_bytes) {
+                double* tri = reinterpret_cast<double*>(static_cast<uint8_t*>(workspace) + part_bytes);
+                k_sym_triangle<<<(unsigned)((ntri + 255) / 256), 256, 0, stream>>>(static_cast<const double*>(dt->table), dt->C, tri);
+                HIP_TRY(hipGetLastError());
+                q.table = tri;
+                kern = k_cost_v3_pairs<kV3Ahead>;
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pairs_lds));
+                const unsigned pgrid = (unsigned)std::min<int64_t>(cus, q.nitems);
+                kern<<<pgrid, kV3Threads, pairs_lds, stream>>>(q);
+                HIP_TRY(hipGetLastError());
+                k_sum_chunks<<<(unsigned)((B + 255) / 256), 256, 0, stream>>>(q.partial, B, pchunks, out);
+                HIP_TRY(hipGetLastError());
+                return QP_OK;
+            }
         }
         if (rowpath && mode == kTabGlobal && dt->kind == QP_DT_F64) {
             // fp64 table too big for LDS: one pass per band of source cores, each with its band in LDS
@@ -1174,7 +1383,7 @@ extern "C" int qp_slice_cost_v2(const QpCircuit* circ, const QpDTable* dt, const
     const bool tab_big = !tab_small && tab_padded <= 144 * 1024;
     const size_t lds = (tab_small || tab_big) ? tab_padded : 0;
     const int threads = tab_big ? 1024 : 256;
-    const int cus = device_cus();
+    const int cus = qp::device_cus();
     void (*kern)(V2Args) = nullptr;
     if (dt->kind == QP_DT_F64)
         kern = tab_small ? k_cost_v2<QP_DT_F64, true, 256> : tab_big ? k_cost_v2<QP_DT_F64, true, 1024> : k_cost_v2<QP_DT_F64, false, 256>;
@@ -1228,4 +1437,11 @@ extern "C" int qp_cost_matrix(int32_t kind, const QpCircuit* circ, const QpDTabl
     else k_cost_matrix<QP_CM_GTRHQA><<<grid, 256, 0, stream>>>(p);
     HIP_TRY(hipGetLastError());
     return QP_OK;
+}
+
+int qp::device_cus() {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 256;
+    return n;
 }

@@ -8,12 +8,6 @@
 
 #include "qplace_internal.h"
 
-#define HIP_TRY(expr)                                                                          \
-    do {                                                                                       \
-        hipError_t e_ = (expr);                                                                \
-        if (e_ != hipSuccess) return qp::fail(QP_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
-    } while (0)
-
 namespace {
 
 typedef int v4i __attribute__((ext_vector_type(4)));

@@ -118,6 +118,11 @@ class DeviceCircuit:
         return 4 * (self.ir.T + 1) + 8 * self.ir.nE
 
 
+# |D[a][b] - D[b][a]| relative to the entry below which a matrix counts as symmetric: costs are compared
+# at 1e-12 relative, a symmetrised entry is off by at most half the asymmetry
+SYMMETRY_TOLERANCE = 1e-13
+
+
 class DistanceTable:
     """A C x C distance matrix on the host (``D``) and on the device in two forms: fp64 (cost
     matrices) and the packed form qp_dtable_pack chooses (uint16 when every entry is an integer)."""
@@ -137,11 +142,16 @@ class DistanceTable:
         self._packed = torch.from_numpy(staging[:padded].copy()).to(self.device)
         # "table": always looked up; "packed": additionally carries the closed form of a grid metric
         # when the matrix is one, and the dense cost kernel then computes distances from core ids
+        # "f64" / "packed" for a real-valued matrix: flagged symmetric when it is one to within rounding
+        # (undirected graphs), which lets a table too large for on-chip memory be replaced by pair counts
         self.table_only = QpDTable(self.kind, self.C, self._packed.data_ptr())
         self.grid = QpGridMetric()
         if self.kind == QP_DT_U16:
             check(lib().qp_dtable_grid_metric(ptr(self.D), self.C, C.byref(self.grid)))
-        self.packed = QpDTable(self.kind, self.C, self._packed.data_ptr(), self.grid)
+        self.symmetric = lib().qp_dtable_symmetric(ptr(self.D), self.C, SYMMETRY_TOLERANCE)
+        check(min(self.symmetric, 0))
+        self.packed = QpDTable(self.kind, self.C, self._packed.data_ptr(), self.grid,
+                               self.symmetric if self.kind == QP_DT_F64 else 0)
         if self.kind == QP_DT_F64:
             self._f64 = self._packed
         else:
@@ -150,7 +160,7 @@ class DistanceTable:
             buf = np.zeros((n * 8 + 15) // 16 * 16, np.uint8)
             buf[:n * 8] = Dz.view(np.uint8).reshape(-1)
             self._f64 = torch.from_numpy(buf).to(self.device)
-        self.f64 = QpDTable(QP_DT_F64, self.C, self._f64.data_ptr())
+        self.f64 = QpDTable(QP_DT_F64, self.C, self._f64.data_ptr(), QpGridMetric(), self.symmetric)
 
     @classmethod
     def from_network(cls, network, device=None, weighted=True):

@@ -142,6 +142,72 @@ def test_cost_v3_random(gpu, Q, T, C, B, integer):
         assert _close(got[b], want, integer), (b, got[b], want)
 
 
+PAIR_SHAPES = [  # Q, T, C, B, chord edges dropped so the graph falls apart, moves per row
+    (1024, 40, 256, 3, False, 0.3), (600, 70, 200, 2, False, 0.05), (1021, 5, 140, 2, False, 1.0),
+    (700, 33, 256, 2, True, 0.3), (1024, 130, 255, 5, False, 0.02),
+]
+
+
+@pytest.mark.parametrize("Q,T,C,B,split,pmove", PAIR_SHAPES)
+def test_cost_v3_pair_counts(gpu, Q, T, C, B, split, pmove):
+    """Real-valued table of more than 134 cores, rows longer than 512 bytes: the default path counts
+    unordered core pairs on chip and multiplies by the symmetrised table once per partition; forcing
+    look-ups ("table") takes the one-pass-per-band kernel.  Both against the oracle at 1e-12 relative
+    (the tolerance the symmetrisation is sized for), including infinite distances."""
+    torch, engine, eng, dev = gpu
+    ir, eu, ev, w, rng = _random_setup(Q, T, C, False, seed=Q * 13 + T)
+    if split:  # two rings that do not touch: distances between them are infinite
+        h = C // 2
+        eu = list(range(C))
+        ev = [(i + 1) % h if i < h else h + (i + 1 - h) % (C - h) for i in range(C)]
+        w = rng.uniform(1, 3, size=C)
+    D = engine.apsp(C, eu, ev, w)
+    dc, dt = engine.DeviceCircuit(ir, dev), engine.DistanceTable(D, dev)
+    assert dt.kind == engine.QP_DT_F64 and dt.symmetric == 1 and dt.packed.symmetric == 1 and dt.table_only.symmetric == 0
+    assert np.isinf(D).any() == split
+    A = np.empty((B, ir.T, dc.ldq), np.uint8)
+    A[:, 0] = rng.integers(0, C, size=(B, dc.ldq), dtype=np.uint8)
+    for t in range(1, ir.T):
+        move = rng.random((B, dc.ldq)) < pmove
+        A[:, t] = np.where(move, rng.integers(0, C, size=(B, dc.ldq), dtype=np.uint8), A[:, t - 1])
+    if split:  # partition 0 stays inside the first ring: finite cost
+        A[0] %= C // 2
+    Ad = torch.from_numpy(A).to(dev)
+    got = eng.cost_v3(dc, dt, Ad).cpu().numpy()
+    band = eng.cost_v3(dc, dt, Ad, table="table").cpu().numpy()
+    Dl = D.tolist()
+    for b in range(B):
+        want = O.cost_v3(ir.slices, ir.gate_q, ir.gate_mr, A[b, :, :Q].tolist(), Dl)
+        if np.isinf(want):
+            assert np.isinf(got[b]) and np.isinf(band[b]), (b, got[b], band[b])
+        else:
+            assert abs(got[b] - want) <= 1e-12 * abs(want), (b, got[b], want)
+            assert abs(band[b] - want) <= 1e-12 * abs(want), (b, band[b], want)
+    if split:
+        assert np.isfinite(got[0]) and np.isinf(got[1:]).all()
+    # run to run the sums are formed in the same order
+    again = eng.cost_v3(dc, dt, Ad).cpu().numpy()
+    assert again.tobytes() == got.tobytes()
+
+
+def test_cost_v3_asymmetric_table_is_looked_up(gpu):
+    """A table that is not symmetric (nothing the placers produce: their graphs are undirected) is never
+    symmetrised: the flag stays clear and directed look-ups give the directed sums."""
+    torch, engine, eng, dev = gpu
+    Q, T, C, B = 1024, 12, 160, 2
+    ir, eu, ev, w, rng = _random_setup(Q, T, C, False, seed=99)
+    D = engine.apsp(C, eu, ev, w)
+    D = D * (1.0 + 0.5 * np.triu(np.ones((C, C)), 1))  # entries above the diagonal 50% larger
+    dc, dt = engine.DeviceCircuit(ir, dev), engine.DistanceTable(D, dev)
+    assert dt.kind == engine.QP_DT_F64 and dt.symmetric == 0 and dt.packed.symmetric == 0
+    A = rng.integers(0, C, size=(B, ir.T, dc.ldq), dtype=np.uint8)
+    got = eng.cost_v3(dc, dt, torch.from_numpy(A).to(dev)).cpu().numpy()
+    Dl = D.tolist()
+    for b in range(B):
+        want = O.cost_v3(ir.slices, ir.gate_q, ir.gate_mr, A[b, :, :Q].tolist(), Dl)
+        assert abs(got[b] - want) <= 1e-12 * abs(want), (b, got[b], want)
+
+
 GRIDS = [  # topology, nx, ny, integer edge weight, closed form expected
     ("mesh", 4, 4, 2.0, True), ("mesh", 2, 8, 3.0, True), ("mesh", 16, 16, 2.0, True), ("mesh", 3, 4, 2.0, True),
     ("mesh", 4, 3, 2.0, False), ("mesh", 8, 2, 5.0, True), ("mesh", 2, 1, 1.0, True), ("line", 7, 1, 1.0, True),
