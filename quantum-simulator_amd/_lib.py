@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libqplace.so")
+# QPLACE_LIB names another build of the same library (development: instrumented kernels, launch knobs)
+LIB_PATH = os.environ.get("QPLACE_LIB") or os.path.join(_HERE, "libqplace.so")
 
 QP_OK = 0
 QP_DT_F64, QP_DT_U16 = 0, 1

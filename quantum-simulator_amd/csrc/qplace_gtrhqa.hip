@@ -10,6 +10,17 @@
 
 #include "qplace_internal.h"
 
+// -DQP_GTRHQA_TIMING (development): thread 0 accumulates clock64() per phase and instance 0 prints them
+#ifdef QP_GTRHQA_TIMING
+#define TIC(slot) do { const long long now_ = clock64(); tacc[slot] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define TIC(slot) do { } while (0)
+#endif
+
+#ifndef QP_GT_WAVES
+#define QP_GT_WAVES 8
+#endif
+
 namespace {
 
 constexpr int kWave = 64;
@@ -93,7 +104,7 @@ __global__ void k_gtrhqa_prepare(const double* D, int C, double* Dz, int32_t* al
 // kThreads = 1024: 16 waves share an instance's bidding (shortest time for one placement);
 // kThreads = 256: more instances resident per CU (highest throughput for large batches).
 template <int kThreads>
-__global__ __launch_bounds__(kThreads) void k_gtrhqa_place(GpArgs p) {
+__global__ __launch_bounds__(kThreads, kThreads == 256 ? QP_GT_WAVES : 4) void k_gtrhqa_place(GpArgs p) {
     constexpr int kWaves = kThreads / kWave;
     extern __shared__ __align__(16) uint8_t smem[];
     __shared__ int s_nops, s_nav, s_nleft, s_nfree, s_flag, s_wave_cnt[kWaves], s_base;
@@ -115,6 +126,10 @@ __global__ __launch_bounds__(kThreads) void k_gtrhqa_place(GpArgs p) {
     // all distances finite: then every entry is, and the "nothing finite left" test never fires
     const bool dfinite = *p.all_finite != 0;
 
+#ifdef QP_GTRHQA_TIMING
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
+    long long n_rounds = 0, n_need = 0, n_left = 0;
+#endif
     for (int64_t b = blockIdx.x; b < p.B; b += gridDim.x) {
         uint8_t* outb = p.out + (size_t)b * (p.T + 1) * ldq;
         for (int k = tid * 16; k < ldq; k += kThreads * 16) {
@@ -195,6 +210,7 @@ __global__ __launch_bounds__(kThreads) void k_gtrhqa_place(GpArgs p) {
                 __syncthreads();
             }
             const int nops = s_nops, nav = s_nav;
+            TIC(0);
             if (nops > 0 && nav > 0) {
                 // A 16-lane row of a wave serves one bidding op; lane l of the row looks at columns l, l + 16, ...
                 // Their cores, four to a register:
@@ -250,6 +266,11 @@ __global__ __launch_bounds__(kThreads) void k_gtrhqa_place(GpArgs p) {
                         __syncthreads();
                     }
                     const int nneed = s_base;
+                    TIC(1);
+#ifdef QP_GTRHQA_TIMING
+                    n_rounds += 1;
+                    n_need += nneed;
+#endif
                     // each of them looks for its cheapest free core (first minimum); four ops per wave step
                     uint32_t fmask = 0;  // bit it: this lane's column it * 16 + l16 exists and is free
 #pragma unroll
@@ -269,16 +290,30 @@ __global__ __launch_bounds__(kThreads) void k_gtrhqa_place(GpArgs p) {
                         // keeps its first minimum and the row minimum breaks ties by column
                         unsigned long long key = ~0ull;
                         uint32_t idx = 0x7FFFFFFFu;
+                        // Eight columns at a time: their 16 loads are issued together, with no branch between
+                        // them (columns past nav repeat the last one and are masked out by fmask), so a step
+                        // costs two memory latencies instead of one per column.
 #pragma unroll
-                        for (int it = 0; it < 16; ++it) {
-                            if (it < nit) {  // uniform
-                                const uint32_t c = (cpk[it >> 2] >> (8 * (it & 3))) & 0xFFu;
-                                const double val = r1[c] + r2[c];
-                                const bool fin = dfinite || isfinite(val);
-                                const unsigned long long kk = dbits(fin ? val : kBig);
-                                if (((fmask >> it) & 1u) && kk < key) {
-                                    key = kk;
-                                    idx = (uint32_t)(it * 16 + l16) | (fin ? 0x10000u : 0u);
+                        for (int h = 0; h < 2; ++h) {
+                            if (h * 8 < nit) {  // uniform
+                                double d1[8], d2[8];
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) {
+                                    const int it = h * 8 + i;
+                                    const uint32_t c = (cpk[it >> 2] >> (8 * (it & 3))) & 0xFFu;
+                                    d1[i] = r1[c];
+                                    d2[i] = r2[c];
+                                }
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) {
+                                    const int it = h * 8 + i;
+                                    const double val = d1[i] + d2[i];
+                                    const bool fin = dfinite || isfinite(val);
+                                    const unsigned long long kk = dbits(fin ? val : kBig);
+                                    if (((fmask >> it) & 1u) && kk < key) {
+                                        key = kk;
+                                        idx = (uint32_t)(it * 16 + l16) | (fin ? 0x10000u : 0u);
+                                    }
                                 }
                             }
                         }
@@ -294,6 +329,7 @@ __global__ __launch_bounds__(kThreads) void k_gtrhqa_place(GpArgs p) {
                         win[j] = ~0u;
                     }
                     __syncthreads();
+                    TIC(2);
                     // a core takes its cheapest bidder, the first one in op order among equals (:150-176)
                     for (int k = tid; k < nops; k += kThreads)
                         if (flags[k].left) atomicMin(&best[target[k]], dbits(bid[k]));
@@ -317,8 +353,12 @@ __global__ __launch_bounds__(kThreads) void k_gtrhqa_place(GpArgs p) {
                     for (int k = tid; k < nops; k += kThreads)
                         if (flags[k].left && !cfree[target[k]]) flags[k].need = 1;
                     __syncthreads();
+                    TIC(3);
                 }
                 // :222-254 what is still open takes its cheapest remaining core, op by op
+#ifdef QP_GTRHQA_TIMING
+                n_left += s_nleft;
+#endif
                 if (s_nleft > 0 && s_nfree > 0) {
                     for (int k = 0; k < nops; ++k) {
                         if (!flags[k].left) continue;  // same value in every thread (read after a barrier)
@@ -360,13 +400,20 @@ __global__ __launch_bounds__(kThreads) void k_gtrhqa_place(GpArgs p) {
                 }
             }
             __syncthreads();
+            TIC(4);
             uint8_t* orow = outb + (size_t)(t + 1) * ldq;
             for (int k = tid * 16; k < ldq; k += kThreads * 16) {  // written once: keep it out of the caches
                 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
                 __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(a + k), reinterpret_cast<u32x4*>(orow + k));
             }
             __syncthreads();
+            TIC(5);
         }
+#ifdef QP_GTRHQA_TIMING
+        if (tid == 0 && b == 0)
+            printf("gtrhqa phases (cycles, instance 0, %d threads): setup %lld  needlist %lld  bid %lld  resolve %lld  leftover %lld  store %lld | rounds %lld  bids %lld  open after the rounds %lld\n",
+                   kThreads, tacc[0], tacc[1], tacc[2], tacc[3], tacc[4], tacc[5], n_rounds, n_need, n_left);
+#endif
     }
 }
 
