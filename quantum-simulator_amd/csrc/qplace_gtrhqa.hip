@@ -17,8 +17,9 @@
 #define TIC(slot) do { } while (0)
 #endif
 
+// waves per SIMD the narrow workgroup is compiled for (register budget 512 / QP_GT_WAVES): 5 measured best
 #ifndef QP_GT_WAVES
-#define QP_GT_WAVES 8
+#define QP_GT_WAVES 5
 #endif
 
 namespace {
@@ -107,7 +108,7 @@ template <int kThreads>
 __global__ __launch_bounds__(kThreads, kThreads == 256 ? QP_GT_WAVES : 4) void k_gtrhqa_place(GpArgs p) {
     constexpr int kWaves = kThreads / kWave;
     extern __shared__ __align__(16) uint8_t smem[];
-    __shared__ int s_nops, s_nav, s_nleft, s_nfree, s_flag, s_wave_cnt[kWaves], s_base;
+    __shared__ int s_nops, s_nav, s_nleft, s_nfree, s_nneed, s_flag, s_wave_cnt[kWaves], s_base;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     const int C = p.C, Q = p.Q, ldq = p.ldq;
     uint8_t* rows = smem + p.off_rows;                                 // [2][ldq]
@@ -215,7 +216,6 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? QP_GT_WAVES : 4) void k
                 // A 16-lane row of a wave serves one bidding op; lane l of the row looks at columns l, l + 16, ...
                 // Their cores, four to a register:
                 const int l16 = lane & 15, rowi = lane >> 4;
-                const int nit = (nav + 15) >> 4;
                 uint32_t cpk[4] = {0, 0, 0, 0};
 #pragma unroll
                 for (int it = 0; it < 16; ++it)
@@ -223,7 +223,9 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? QP_GT_WAVES : 4) void k
                 if (tid == 0) {
                     s_nleft = nops;
                     s_nfree = nav;
+                    s_nneed = nops;
                 }
+                for (int k = tid; k < nops; k += kThreads) need_list[k] = (uint16_t)k;
                 __syncthreads();
                 const int max_rounds = min(nav, nops) + 2;
                 int rounds = 0;
@@ -245,27 +247,9 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? QP_GT_WAVES : 4) void k
                         __syncthreads();
                         if (!go) break;
                     }
-                    // the ops without a standing bid, in op order
-                    if (tid == 0) s_base = 0;
-                    __syncthreads();
-                    for (int kb0 = 0; kb0 < nops; kb0 += kThreads) {
-                        const int k = kb0 + tid;
-                        const bool has = k < nops && flags[k].left && flags[k].need;
-                        const unsigned long long m = __ballot(has);
-                        if (lane == 0) s_wave_cnt[wave] = __popcll(m);
-                        __syncthreads();
-                        int base = s_base;
-                        for (int w = 0; w < wave; ++w) base += s_wave_cnt[w];
-                        if (has) need_list[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)k;
-                        __syncthreads();
-                        if (tid == 0) {
-                            int n = s_base;
-                            for (int w = 0; w < kWaves; ++w) n += s_wave_cnt[w];
-                            s_base = n;
-                        }
-                        __syncthreads();
-                    }
-                    const int nneed = s_base;
+                    // the ops without a standing bid: all of them in the first round, afterwards the ones the
+                    // last round's settlement put on the list (in no particular order: bids are independent)
+                    const int nneed = s_nneed;
                     TIC(1);
 #ifdef QP_GTRHQA_TIMING
                     n_rounds += 1;
@@ -290,30 +274,25 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? QP_GT_WAVES : 4) void k
                         // keeps its first minimum and the row minimum breaks ties by column
                         unsigned long long key = ~0ull;
                         uint32_t idx = 0x7FFFFFFFu;
-                        // Eight columns at a time: their 16 loads are issued together, with no branch between
-                        // them (columns past nav repeat the last one and are masked out by fmask), so a step
-                        // costs two memory latencies instead of one per column.
+                        // The 32 loads of a lane's 16 columns are issued together, with no branch between them
+                        // (columns past nav repeat the last one and are masked out by fmask): a step costs one
+                        // memory latency, not one per column.
+                        {
+                            double d1[16], d2[16];
 #pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            if (h * 8 < nit) {  // uniform
-                                double d1[8], d2[8];
+                            for (int it = 0; it < 16; ++it) {
+                                const uint32_t c = (cpk[it >> 2] >> (8 * (it & 3))) & 0xFFu;
+                                d1[it] = r1[c];
+                                d2[it] = r2[c];
+                            }
 #pragma unroll
-                                for (int i = 0; i < 8; ++i) {
-                                    const int it = h * 8 + i;
-                                    const uint32_t c = (cpk[it >> 2] >> (8 * (it & 3))) & 0xFFu;
-                                    d1[i] = r1[c];
-                                    d2[i] = r2[c];
-                                }
-#pragma unroll
-                                for (int i = 0; i < 8; ++i) {
-                                    const int it = h * 8 + i;
-                                    const double val = d1[i] + d2[i];
-                                    const bool fin = dfinite || isfinite(val);
-                                    const unsigned long long kk = dbits(fin ? val : kBig);
-                                    if (((fmask >> it) & 1u) && kk < key) {
-                                        key = kk;
-                                        idx = (uint32_t)(it * 16 + l16) | (fin ? 0x10000u : 0u);
-                                    }
+                            for (int it = 0; it < 16; ++it) {
+                                const double val = d1[it] + d2[it];
+                                const bool fin = dfinite || isfinite(val);
+                                const unsigned long long kk = dbits(fin ? val : kBig);
+                                if (((fmask >> it) & 1u) && kk < key) {
+                                    key = kk;
+                                    idx = (uint32_t)(it * 16 + l16) | (fin ? 0x10000u : 0u);
                                 }
                             }
                         }
@@ -328,7 +307,8 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? QP_GT_WAVES : 4) void k
                         best[j] = ~0ull;
                         win[j] = ~0u;
                     }
-                    __syncthreads();
+                    __syncthreads();         // every thread has read s_nneed and is done with the list
+                    if (tid == 0) s_nneed = 0;  // (ordered before the appends below by the barriers in between)
                     TIC(2);
                     // a core takes its cheapest bidder, the first one in op order among equals (:150-176)
                     for (int k = tid; k < nops; k += kThreads)
@@ -350,8 +330,22 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? QP_GT_WAVES : 4) void k
                         atomicSub(&s_nfree, 1);
                     }
                     __syncthreads();
-                    for (int k = tid; k < nops; k += kThreads)
-                        if (flags[k].left && !cfree[target[k]]) flags[k].need = 1;
+                    for (int kb0 = 0; kb0 < nops; kb0 += kThreads) {
+                        const int k = kb0 + tid;
+                        // its core went to someone else: bid again (one list-counter update per wave)
+                        const bool again = k < nops && flags[k].left && !cfree[target[k]];
+                        const unsigned long long m = __ballot(again);
+                        if (m) {
+                            const int leader = __ffsll((long long)m) - 1;
+                            int base = 0;
+                            if (lane == leader) base = atomicAdd(&s_nneed, __popcll(m));
+                            base = __builtin_amdgcn_readlane(base, leader);
+                            if (again) {
+                                flags[k].need = 1;
+                                need_list[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)k;
+                            }
+                        }
+                    }
                     __syncthreads();
                     TIC(3);
                 }
