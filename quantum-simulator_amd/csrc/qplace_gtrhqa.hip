@@ -17,9 +17,9 @@
 #define TIC(slot) do { } while (0)
 #endif
 
-// waves per SIMD the narrow workgroup is compiled for (register budget 512 / QP_GT_WAVES): 5 measured best
+// waves per SIMD the narrow workgroup is compiled for (register budget 512 / QP_GT_WAVES): 6 measured best
 #ifndef QP_GT_WAVES
-#define QP_GT_WAVES 5
+#define QP_GT_WAVES 6
 #endif
 
 namespace {
@@ -267,8 +267,9 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? QP_GT_WAVES : 4) void k
                         const bool act = e < nneed;
                         const int k = need_list[act ? e : nb];  // a row without an op of its own repeats the first
                         const uint32_t a1 = a12[k] & 0xFF, a2 = a12[k] >> 8;
-                        const double* r1 = p.D + (size_t)a1 * C;
-                        const double* r2 = p.D + (size_t)a2 * C;
+                        // rows of the table as 32-bit byte offsets from its (uniform) base: one register per address
+                        const char* dbase = reinterpret_cast<const char*>(p.D);
+                        const uint32_t r1 = a1 * (uint32_t)C * 8u, r2 = a2 * (uint32_t)C * 8u;
                         // key = bits of the entry (non-negative doubles order like their bits), idx = column
                         // with "finite" in bit 16; a lane looks at its columns in ascending order, so "<"
                         // keeps its first minimum and the row minimum breaks ties by column
@@ -281,9 +282,9 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? QP_GT_WAVES : 4) void k
                             double d1[16], d2[16];
 #pragma unroll
                             for (int it = 0; it < 16; ++it) {
-                                const uint32_t c = (cpk[it >> 2] >> (8 * (it & 3))) & 0xFFu;
-                                d1[it] = r1[c];
-                                d2[it] = r2[c];
+                                const uint32_t c8 = ((cpk[it >> 2] >> (8 * (it & 3))) & 0xFFu) * 8u;
+                                d1[it] = *reinterpret_cast<const double*>(dbase + (r1 + c8));
+                                d2[it] = *reinterpret_cast<const double*>(dbase + (r2 + c8));
                             }
 #pragma unroll
                             for (int it = 0; it < 16; ++it) {
