@@ -253,15 +253,15 @@ def main():
         if dt.kind == QP_DT_U16:
             how = ("none: closed-form grid metric (v_sad_u8 on packed core ids), verified against the matrix"
                    if closed else "uint16, LDS-resident")
-            kname = "k_cost_v3_row<u16, grid>" if closed else "k_cost_v3_row<u16, lds256>"
+            kname = "k_cost_v3_grid_row<false, 4>" if closed else "k_cost_v3_row<1, 0, 4>"  # names as rocprofv3 prints them
         elif C * C * 8 <= 128 * 1024:
-            how, kname = "f64, LDS-resident", "k_cost_v3_row<f64, lds>"
+            how, kname = "f64, LDS-resident", "k_cost_v3_row<0, 0, 4>"
         elif table == "packed" and dt.symmetric:
             how = ("f64, 512 KB (too large for LDS), symmetric to rounding: core pairs are counted in LDS "
                    "(uint32 per unordered pair), one product with the table per partition")
-            kname = "k_cost_v3_pairs"
+            kname = "k_cost_v3_pairs<4>"
         else:
-            how, kname = "f64, 512 KB: LDS-resident in 4 bands of source cores, one pass per band", "k_cost_v3_row<f64, band> x4"
+            how, kname = "f64, 512 KB: LDS-resident in 4 bands of source cores, one pass per band", "k_cost_v3_row<0, 3, 4> x4"
         for _ in range(args.warmup):
             eng.cost_v3(dc, dt, A, out=out, table=table)
         torch.cuda.synchronize(dev)
