@@ -1040,6 +1040,7 @@ __global__ __launch_bounds__(256) void k_cost_matrix(CmArgs p) {
     __shared__ __align__(16) int32_t opinfo[kCmOps][8];  // [0..5] partner cores (-1 = none), [6] a1, [7] a2
     __shared__ double att_far[kCmOps];                   // attraction seen from a core that holds no partner
     __shared__ uint32_t near_mask[kCmOps][8];            // bit c: core c holds a look-ahead partner
+    __shared__ double att_near[kCmOps][6];               // attraction seen from the core of partner k
     const int64_t b = blockIdx.y;
     const int n_ops = p.n_ops[b], n_av = p.n_avail[b];
     const int i0 = blockIdx.x * kCmOps;
@@ -1060,6 +1061,11 @@ __global__ __launch_bounds__(256) void k_cost_matrix(CmArgs p) {
         opinfo[threadIdx.x >> 3][k] = v;
     }
     __syncthreads();
+    if (threadIdx.x < kCmOps * 8 && (threadIdx.x & 7) < 6) {  // once per op and partner, not once per column
+        const int32_t* pc = opinfo[threadIdx.x >> 3];
+        const int32_t c = pc[threadIdx.x & 7];
+        att_near[threadIdx.x >> 3][threadIdx.x & 7] = c >= 0 ? cm_attraction(pc, c) : 0.0;
+    }
     if (threadIdx.x < kCmOps) {
         const int32_t* pc = opinfo[threadIdx.x];
         att_far[threadIdx.x] = cm_attraction(pc, -2);  // -2 equals no core
@@ -1106,7 +1112,13 @@ __global__ __launch_bounds__(256) void k_cost_matrix(CmArgs p) {
                 r = cost;
             } else {
                 double att = att_far[i];
-                if ((near_mask[i][c >> 5] >> (c & 31)) & 1u) att = cm_attraction(opinfo[i], c);
+                if ((near_mask[i][c >> 5] >> (c & 31)) & 1u) {
+                    // the sum depends on the core only: take it from any partner slot that sits on this core
+                    int slot = 0;
+#pragma unroll
+                    for (int k = 1; k < 6; ++k) slot = opinfo[i][k] == c ? k : slot;
+                    att = att_near[i][slot];
+                }
                 if constexpr (KINDC == QP_CM_HQA) {
                     const double m = (double)((a1 != c) + (a2 != c));
                     r = pymax(0.1, pymax(0.1, m - att));
