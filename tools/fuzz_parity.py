@@ -1,0 +1,74 @@
+"""Randomised differential run of the device kernels against the CPU oracle: draws shapes the fixed
+parametrisations of tests/ do not list and calls the same test bodies with them.
+fuzz_parity.py [seconds=120] [seed=0]   (run on a GPU box from the repository root; exits non-zero on a mismatch)"""
+import os
+import sys
+import time
+import traceback
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import test_gpu_cost as TC  # noqa: E402
+import test_gpu_placers as TP  # noqa: E402
+from quantum_simulator_amd import engine  # noqa: E402
+
+
+def unwrap(f):
+    return getattr(f, "__wrapped__", f)
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    dev = torch.device("cuda", 0)
+    gpu = (torch, engine, engine.Engine(dev), dev)
+    t0 = time.time()
+    runs, fails = {}, 0
+
+    def pick(lo, hi):
+        return int(rng.integers(lo, hi + 1))
+
+    def wide_q():  # favour the row-length classes the launchers switch on (<= 512, 513..1024, > 1024)
+        return [pick(2, 80), pick(81, 512), pick(513, 1024), pick(1025, 1600)][pick(0, 3)]
+
+    def draw():
+        kind = pick(0, 4)
+        if kind == 0:
+            return "cost_v3_random", TC.test_cost_v3_random, (gpu, wide_q(), pick(1, 45), pick(2, 256), pick(1, 6), bool(pick(0, 1)))
+        if kind == 1:
+            return "cost_v2_random", TC.test_cost_v2_random, (gpu, wide_q(), pick(1, 40), pick(2, 255), pick(1, 9), bool(pick(0, 1)))
+        if kind == 2:
+            return "cost_v3_pair_counts", TC.test_cost_v3_pair_counts, (gpu, pick(513, 1024), pick(1, 140), pick(136, 256), pick(1, 5),
+                                                                         bool(pick(0, 3) == 0), float(rng.choice([0.02, 0.3, 1.0])))
+        if kind == 3:
+            C = pick(2, 256)
+            cap = pick(2, 10)
+            Q = min(pick(2, 1024), C * cap)
+            return "gtrhqa_place", TP.test_gtrhqa_device_placement_matches_oracle, (Q, pick(1, 14), C, cap, pick(1, 4), bool(pick(0, 4) == 0 and C >= 6))
+        return "core_activity", TP.test_core_activity_and_comm_matrix_random, (wide_q() if pick(0, 1) else pick(2, 300), pick(1, 60), pick(2, 256), pick(1, 4))
+
+    while time.time() - t0 < budget:
+        name, fn, args = draw()
+        shown = args[1:] if args and args[0] is gpu else args
+        try:
+            c0 = time.time()
+            unwrap(fn)(*args)
+            runs[name] = runs.get(name, 0) + 1
+            if os.environ.get("QP_FUZZ_VERBOSE"):
+                print(f"ok {name}{shown} {time.time() - c0:.3f} s", flush=True)
+        except BaseException as e:  # AssertionError and anything a launch raises
+            if isinstance(e, KeyboardInterrupt):
+                raise
+            fails += 1
+            print(f"FAIL {name}{shown}: {type(e).__name__}: {str(e)[:300]}", flush=True)
+            traceback.print_exc(limit=3)
+    print(f"{sum(runs.values())} cases passed in {time.time() - t0:.0f} s: {runs}; {fails} failed", flush=True)
+    sys.exit(1 if fails else 0)
+
+
+if __name__ == "__main__":
+    main()
