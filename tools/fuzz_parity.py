@@ -21,6 +21,56 @@ def unwrap(f):
     return getattr(f, "__wrapped__", f)
 
 
+def cost_matrix_case(gpu, Q, T, C, cap, kind, seed):
+    """Every op x core matrix the oracle's placement loop builds on a random circuit, bit for bit (the body of
+    tests/test_gpu_cost.py::test_cost_matrix_bits on a circuit drawn here instead of a fixture)."""
+    from oracle import placer_oracle as O
+    from quantum_simulator_amd import layered_gate_arrays
+    from quantum_simulator_amd.timeslices import CircuitIR
+    _, eng_mod, eng, dev = gpu
+    rng = np.random.default_rng(seed)
+    q0, q1, _ = layered_gate_arrays(Q, T, float(rng.choice([0.3, 0.6, 0.9])), seed=seed)
+    keep = rng.random(len(q0)) > 0.2
+    ir = CircuitIR.from_gate_tables(Q, q0[keep], q1[keep])
+    eu = list(range(C)) + [int(x) for x in rng.integers(0, C, size=C // 2)]
+    ev = [(i + 1) % C for i in range(C)] + [int(x) for x in rng.integers(0, C, size=C // 2)]
+    ok = [k for k in range(len(eu)) if eu[k] != ev[k]]
+    eu, ev = [eu[k] for k in ok], [ev[k] for k in ok]
+    D = eng_mod.apsp(C, eu, ev, rng.uniform(1, 3, size=len(eu)))
+    dc, dt = eng_mod.DeviceCircuit(ir, dev), eng_mod.DistanceTable(D, dev)
+    rec, Dl = [], D.tolist()
+    try:
+        if kind == "gtrhqa":
+            O.place_gtrhqa(ir.slices, ir.gate_q, ir.gate_mr, Q, C, cap, Dl, rec)
+        else:
+            O.place_hqa_family(ir.slices, ir.gate_q, ir.gate_mr, Q, C, cap, Dl, kind, rec)
+    except Exception:  # the reference gives up on this instance (no room): matrices up to there still count
+        pass
+    rec = rec[:300]
+    if not rec:
+        return
+    B = len(rec)
+    max_ops = max(len(r[1]) for r in rec)
+    t = np.array([r[0] for r in rec], np.int32)
+    a = np.zeros((B, dc.ldq), np.uint8)
+    ops = np.zeros((B, max_ops), np.int32)
+    n_ops = np.zeros(B, np.int32)
+    avail = np.zeros((B, C), np.uint8)
+    n_avail = np.zeros(B, np.int32)
+    for b, (tt, rops, rav, M, live) in enumerate(rec):
+        a[b, :Q] = live
+        ops[b, :len(rops)] = [ir.edge_of_gate[g] for g, _, _ in rops]
+        n_ops[b] = len(rops)
+        avail[b, :len(rav)] = rav
+        n_avail[b] = len(rav)
+    code = {"hqa": eng_mod.QP_CM_HQA, "trhqa": eng_mod.QP_CM_TRHQA, "gtrhqa": eng_mod.QP_CM_GTRHQA}[kind]
+    out = eng.cost_matrix(code, dc, dt, *[torch.from_numpy(x).to(dev) for x in (t, a, ops, n_ops, avail, n_avail)]).cpu().numpy()
+    for b, (tt, rops, rav, M, live) in enumerate(rec):
+        want = np.array(M, np.float64).reshape(len(rops), len(rav))
+        got = out[b, :len(rops), :len(rav)]
+        assert got.tobytes() == want.tobytes(), (kind, b, tt)
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
@@ -36,7 +86,12 @@ def main():
         return [pick(2, 80), pick(81, 512), pick(513, 1024), pick(1025, 1600)][pick(0, 3)]
 
     def draw():
-        kind = pick(0, 4)
+        kind = pick(0, 5)
+        if kind == 5:
+            C = pick(2, 256)
+            cap = pick(2, 8)
+            Q = min(pick(4, 400), C * cap)
+            return "cost_matrix", cost_matrix_case, (gpu, Q, pick(2, 10), C, cap, ["hqa", "trhqa", "gtrhqa"][pick(0, 2)], pick(0, 1 << 30))
         if kind == 0:
             return "cost_v3_random", TC.test_cost_v3_random, (gpu, wide_q(), pick(1, 45), pick(2, 256), pick(1, 6), bool(pick(0, 1)))
         if kind == 1:
