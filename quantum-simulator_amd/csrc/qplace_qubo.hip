@@ -38,6 +38,46 @@ struct GemmArgs {
     int32_t Npad, R;
 };
 
+// What a workgroup does with its accumulators: store the fields, or fold them into the replicas' energies.
+template <bool ENERGY, int WN>
+__device__ inline void gemm_epilogue(const GemmArgs& p, v16i (&acc)[2][WN], int64_t v0, int r0, int wm, int wn, int lane) {
+    // accumulator element k of lane l: row (k & 3) + 8 * (k >> 2) + 4 * (l >> 5), column l & 31
+    const int h = lane >> 5;
+    if constexpr (!ENERGY) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < WN; ++b) {
+                const int col = r0 + wn * 32 * WN + b * 32 + (lane & 31);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int64_t row = v0 + wm * 64 + a * 32 + (k & 3) + 8 * (k >> 2) + 4 * h;
+                    p.out[(size_t)row * p.R + col] = acc[a][b][k];
+                }
+            }
+    } else {
+#pragma unroll
+        for (int b = 0; b < WN; ++b) {
+            const int col = r0 + wn * 32 * WN + b * 32 + (lane & 31);
+            int s = 0;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int64_t row = v0 + wm * 64 + a * 32 + 8 * g + 4 * h;
+                    const uint32_t x4 = *reinterpret_cast<const uint32_t*>(p.Xt + (size_t)col * p.Npad + row);
+                    const int4 lin = *reinterpret_cast<const int4*>(p.linear + row);
+                    const int l4[4] = {lin.x, lin.y, lin.z, lin.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if ((x4 >> (8 * j)) & 1u) s += 2 * l4[j] + acc[a][b][4 * g + j];
+                }
+            s += __shfl_xor(s, 32, 64);
+            if (h == 0) atomicAdd(&p.out[col], s);
+        }
+    }
+}
+
 // WN = MFMA tiles per wave along the replica axis: 2 (128 replicas per workgroup) or 4 (256).  With 4, a
 // wave feeds 8 MFMAs from 6 fragment reads instead of 4 from 4, which is what the LDS read rate allows.
 template <bool ENERGY, int WN>
@@ -47,7 +87,7 @@ __global__ __launch_bounds__(256, 2) void k_qubo_gemm(GemmArgs p) {
     __shared__ __align__(16) int8_t sB[kCols * kPitch];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int rowtile = blockIdx.x, coltile = blockIdx.y;
+    const int rowtile = blockIdx.y, coltile = blockIdx.x;  // the column tiles of one row tile run side by side: S is read from HBM once
     const int t = p.tile_slice[rowtile];
     const int64_t v0 = (int64_t)rowtile * kTile;     // first variable (padded axis) of this tile
     const int64_t vrow = v0 - p.off[t];              // row inside the slice's blocks
@@ -132,41 +172,7 @@ __global__ __launch_bounds__(256, 2) void k_qubo_gemm(GemmArgs p) {
     }
 
 #undef QP_LOAD_TILE
-    // accumulator element k of lane l: row (k & 3) + 8 * (k >> 2) + 4 * (l >> 5), column l & 31
-    const int h = lane >> 5;
-    if constexpr (!ENERGY) {
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < WN; ++b) {
-                const int col = r0 + wn * 32 * WN + b * 32 + (lane & 31);
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const int64_t row = v0 + wm * 64 + a * 32 + (k & 3) + 8 * (k >> 2) + 4 * h;
-                    p.out[(size_t)row * p.R + col] = acc[a][b][k];
-                }
-            }
-    } else {
-#pragma unroll
-        for (int b = 0; b < WN; ++b) {
-            const int col = r0 + wn * 32 * WN + b * 32 + (lane & 31);
-            int s = 0;
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int64_t row = v0 + wm * 64 + a * 32 + 8 * g + 4 * h;
-                    const uint32_t x4 = *reinterpret_cast<const uint32_t*>(p.Xt + (size_t)col * p.Npad + row);
-                    const int4 lin = *reinterpret_cast<const int4*>(p.linear + row);
-                    const int l4[4] = {lin.x, lin.y, lin.z, lin.w};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if ((x4 >> (8 * j)) & 1u) s += 2 * l4[j] + acc[a][b][4 * g + j];
-                }
-            s += __shfl_xor(s, 32, 64);
-            if (h == 0) atomicAdd(&p.out[col], s);
-        }
-    }
+    gemm_epilogue<ENERGY, WN>(p, acc, v0, r0, wm, wn, lane);
 }
 
 // energy2[r] -> constant + energy2[r] / 2
@@ -409,9 +415,9 @@ GemmArgs gemm_args(const QpQuboDense* m, const int8_t* Xt, int32_t R, int32_t* o
 extern "C" int qp_qubo_fields_i32(const QpQuboDense* m, const int8_t* Xt, int32_t R, int32_t* F, void* stream_) {
     if (int rc = check_dense("qp_qubo_fields_i32", m, Xt, R, F)) return rc;
     if (R % 256 == 0)
-        k_qubo_gemm<false, 4><<<dim3(m->Npad / kTile, R / 256), 256, 0, static_cast<hipStream_t>(stream_)>>>(gemm_args(m, Xt, R, F));
+        k_qubo_gemm<false, 4><<<dim3(R / 256, m->Npad / kTile), 256, 0, static_cast<hipStream_t>(stream_)>>>(gemm_args(m, Xt, R, F));
     else
-        k_qubo_gemm<false, 2><<<dim3(m->Npad / kTile, R / 128), 256, 0, static_cast<hipStream_t>(stream_)>>>(gemm_args(m, Xt, R, F));
+        k_qubo_gemm<false, 2><<<dim3(R / 128, m->Npad / kTile), 256, 0, static_cast<hipStream_t>(stream_)>>>(gemm_args(m, Xt, R, F));
     HIP_TRY(hipGetLastError());
     return QP_OK;
 }
@@ -421,9 +427,9 @@ extern "C" int qp_qubo_energy_i32(const QpQuboDense* m, const int8_t* Xt, int32_
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     HIP_TRY(hipMemsetAsync(energy, 0, (size_t)R * sizeof(int32_t), stream));
     if (R % 256 == 0)
-        k_qubo_gemm<true, 4><<<dim3(m->Npad / kTile, R / 256), 256, 0, stream>>>(gemm_args(m, Xt, R, energy));
+        k_qubo_gemm<true, 4><<<dim3(R / 256, m->Npad / kTile), 256, 0, stream>>>(gemm_args(m, Xt, R, energy));
     else
-        k_qubo_gemm<true, 2><<<dim3(m->Npad / kTile, R / 128), 256, 0, stream>>>(gemm_args(m, Xt, R, energy));
+        k_qubo_gemm<true, 2><<<dim3(R / 128, m->Npad / kTile), 256, 0, stream>>>(gemm_args(m, Xt, R, energy));
     HIP_TRY(hipGetLastError());
     k_qubo_finish<<<(R + 255) / 256, 256, 0, stream>>>(energy, R, m->constant);
     HIP_TRY(hipGetLastError());
