@@ -31,7 +31,8 @@ struct GpArgs {
     const int32_t* sep;
     const QpEdge* edges;
     const double* D;            // prepared copy (row 0 and diagonal zero)
-    const int32_t* all_finite;  // 1 when every distance is finite
+    const uint16_t* D16;        // the same as 16-bit integers; only meaningful when flags[1] is set
+    const int32_t* all_finite;  // [0] 1 when every distance is finite, [1] 1 when every distance is an integer <= 32767
     const uint8_t* initial;
     uint8_t* out;
     int64_t B;
@@ -87,19 +88,28 @@ __device__ inline double entry(const double* Dz, int C, uint32_t a1, uint32_t a2
     return Dz[a1 * C + c] + Dz[a2 * C + c];
 }
 
-// Dz = D with row 0 and the diagonal zeroed; flag = 1 when every entry of D is finite.
-__global__ void k_gtrhqa_prepare(const double* D, int C, double* Dz, int32_t* all_finite) {
-    __shared__ int bad;
-    if (threadIdx.x == 0) bad = 0;
+// Dz = D with row 0 and the diagonal zeroed, Dz16 the same as 16-bit integers; flags[0] = 1 when every entry
+// of D is finite, flags[1] = 1 when every entry is an integer <= 32767 (integer edge weights): the sum of two
+// then fits 16 bits, is exact in either arithmetic, and the bids can be formed from the small table.
+__global__ void k_gtrhqa_prepare(const double* D, int C, double* Dz, uint16_t* Dz16, int32_t* flags) {
+    __shared__ int bad, frac;
+    if (threadIdx.x == 0) bad = frac = 0;
     __syncthreads();
     for (int k = threadIdx.x; k < C * C; k += blockDim.x) {
         const int r = k / C, c = k - r * C;
         const double v = D[k];
         if (!isfinite(v)) bad = 1;
-        Dz[k] = (r == 0 || r == c) ? 0.0 : v;
+        const bool small_int = v >= 0.0 && v <= 32767.0 && v == floor(v);
+        if (!small_int) frac = 1;
+        const bool zero = r == 0 || r == c;
+        Dz[k] = zero ? 0.0 : v;
+        Dz16[k] = zero || !small_int ? (uint16_t)0 : (uint16_t)v;
     }
     __syncthreads();
-    if (threadIdx.x == 0) *all_finite = bad ? 0 : 1;
+    if (threadIdx.x == 0) {
+        flags[0] = bad ? 0 : 1;
+        flags[1] = (bad || frac) ? 0 : 1;
+    }
 }
 
 // kThreads = 1024: 16 waves share an instance's bidding (shortest time for one placement);
@@ -125,7 +135,8 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? QP_GT_WAVES : 4) void k
     uint16_t* need_list = reinterpret_cast<uint16_t*>(smem + p.off_need);  // [max_ops] ops that must bid again
 
     // all distances finite: then every entry is, and the "nothing finite left" test never fires
-    const bool dfinite = *p.all_finite != 0;
+    const bool dfinite = p.all_finite[0] != 0;
+    const bool dsmallint = p.all_finite[1] != 0;
 
 #ifdef QP_GTRHQA_TIMING
     long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
@@ -278,7 +289,30 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? QP_GT_WAVES : 4) void k
                         // The 32 loads of a lane's 16 columns are issued together, with no branch between them
                         // (columns past nav repeat the last one and are masked out by fmask): a step costs one
                         // memory latency, not one per column.
-                        {
+                        if (dsmallint) {  // (uniform) integer table: 2-byte loads, 32-bit sums and compares
+                            const char* hbase = reinterpret_cast<const char*>(p.D16);
+                            const uint32_t h1 = r1 >> 2, h2 = r2 >> 2;
+                            uint32_t s1[16], s2[16];
+#pragma unroll
+                            for (int it = 0; it < 16; ++it) {
+                                const uint32_t c2 = ((cpk[it >> 2] >> (8 * (it & 3))) & 0xFFu) * 2u;
+                                s1[it] = *reinterpret_cast<const uint16_t*>(hbase + (h1 + c2));
+                                s2[it] = *reinterpret_cast<const uint16_t*>(hbase + (h2 + c2));
+                            }
+                            uint32_t key32 = ~0u, best_it = 0;
+#pragma unroll
+                            for (int it = 0; it < 16; ++it) {
+                                const uint32_t kk = s1[it] + s2[it];
+                                if (((fmask >> it) & 1u) && kk < key32) {
+                                    key32 = kk;
+                                    best_it = (uint32_t)it;
+                                }
+                            }
+                            if (key32 != ~0u) {  // the same bits the fp64 sum of the two (integer) entries has
+                                key = dbits((double)key32);
+                                idx = (best_it * 16u + (uint32_t)l16) | 0x10000u;
+                            }
+                        } else {
                             double d1[16], d2[16];
 #pragma unroll
                             for (int it = 0; it < 16; ++it) {
@@ -415,7 +449,8 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? QP_GT_WAVES : 4) void k
 }  // namespace
 
 extern "C" size_t qp_gtrhqa_workspace(int32_t C) {
-    return C > 0 ? (size_t)C * C * sizeof(double) + 16 : 16;
+    // fp64 copy, two flags, 16-bit copy
+    return C > 0 ? (size_t)C * C * (sizeof(double) + sizeof(uint16_t)) + 16 : 16;
 }
 
 extern "C" int qp_gtrhqa_place(const QpCircuit* circ, const QpDTable* dt, const uint8_t* initial, int64_t B, int32_t ldq,
@@ -434,7 +469,8 @@ extern "C" int qp_gtrhqa_place(const QpCircuit* circ, const QpDTable* dt, const 
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     double* Dz = static_cast<double*>(workspace);
     int32_t* all_finite = reinterpret_cast<int32_t*>(Dz + (size_t)dt->C * dt->C);
-    k_gtrhqa_prepare<<<1, 1024, 0, stream>>>(static_cast<const double*>(dt->table), dt->C, Dz, all_finite);
+    uint16_t* Dz16 = reinterpret_cast<uint16_t*>(all_finite + 4);
+    k_gtrhqa_prepare<<<1, 1024, 0, stream>>>(static_cast<const double*>(dt->table), dt->C, Dz, Dz16, all_finite);
     HIP_TRY(hipGetLastError());
 
     // the most counted gates any slice has sizes the per-op arrays: the caller's figure if it gave one
@@ -444,6 +480,7 @@ extern "C" int qp_gtrhqa_place(const QpCircuit* circ, const QpDTable* dt, const 
     p.sep = circ->slice_edge_ptr;
     p.edges = circ->edges;
     p.D = Dz;
+    p.D16 = Dz16;
     p.all_finite = all_finite;
     p.initial = initial;
     p.out = out;
