@@ -248,7 +248,8 @@ int qp_cost_matrix(int32_t kind, const QpCircuit* circ, const QpDTable* dt, int6
  * initial: dev uint8 [B][ldq] core index per qubit (< C; row 0 of every instance).  out: dev uint8
  * [B][T+1][ldq]; row 0 is a copy of initial (pad columns included), the rest follow.
  * dt must be QP_DT_F64.  The caller checks what the reference checks before it starts (capacity).
- * workspace: dev, qp_gtrhqa_workspace(C) bytes, 8-byte aligned (a prepared copy of the table). */
+ * workspace: dev, qp_gtrhqa_workspace(C) bytes, 8-byte aligned (prepared copies of the table: fp64, and 16-bit
+ * for tables of small integers, which the call detects itself). */
 size_t qp_gtrhqa_workspace(int32_t C);
 int qp_gtrhqa_place(const QpCircuit* circ, const QpDTable* dt, const uint8_t* initial, int64_t B, int32_t ldq,
                     int32_t cap, uint8_t* out, void* workspace, size_t workspace_bytes, void* stream);

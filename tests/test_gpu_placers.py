@@ -152,17 +152,21 @@ def test_place_batch_lockstep(name, pname):
         assert (got[b] == np.array(want, np.uint8)).all(), (pname, b)
 
 
-GTR_SHAPES = [  # Q, T, C, cap, instances, disconnected graph
-    (40, 30, 8, 6, 4, False), (200, 20, 32, 8, 5, False), (33, 12, 5, 8, 3, False), (64, 15, 16, 4, 4, False),
-    (48, 10, 8, 6, 3, True), (300, 8, 64, 6, 3, True), (1024, 5, 256, 8, 3, False), (16, 9, 8, 2, 2, False),
+GTR_SHAPES = [  # Q, T, C, cap, instances, disconnected graph, integer edge weights
+    (40, 30, 8, 6, 4, False, False), (200, 20, 32, 8, 5, False, False), (33, 12, 5, 8, 3, False, False),
+    (64, 15, 16, 4, 4, False, False), (48, 10, 8, 6, 3, True, False), (300, 8, 64, 6, 3, True, False),
+    (1024, 5, 256, 8, 3, False, False), (16, 9, 8, 2, 2, False, False),
+    (40, 30, 8, 6, 4, False, True), (200, 20, 32, 8, 5, False, True), (1024, 5, 256, 8, 3, False, True),
+    (300, 8, 64, 6, 3, True, True), (64, 15, 16, 4, 4, False, True),
 ]
 
 
-@pytest.mark.parametrize("Q,T,C,cap,B,disconnected", GTR_SHAPES)
-def test_gtrhqa_device_placement_matches_oracle(Q, T, C, cap, B, disconnected):
+@pytest.mark.parametrize("Q,T,C,cap,B,disconnected,integer", GTR_SHAPES)
+def test_gtrhqa_device_placement_matches_oracle(Q, T, C, cap, B, disconnected, integer):
     """qp_gtrhqa_place (every slice on the device) against the sequential restatement, row for row,
-    from shuffled starting assignments; includes graphs with unreachable cores (infinite distances)
-    and capacities that leave few or no cores with room."""
+    from shuffled starting assignments; includes graphs with unreachable cores (infinite distances),
+    capacities that leave few or no cores with room, and integer edge weights (many equal bids; the
+    kernel then forms its bids from a 16-bit copy of the table)."""
     import torch
     from oracle import placer_oracle as O
     from quantum_simulator_amd import engine, layered_gate_arrays
@@ -181,7 +185,7 @@ def test_gtrhqa_device_placement_matches_oracle(Q, T, C, cap, B, disconnected):
         ev = [(i + 1) % C for i in range(C)] + [int(x) for x in rng.integers(0, C, size=C // 2)]
     ok = [k for k in range(len(eu)) if eu[k] != ev[k]]
     eu, ev = [eu[k] for k in ok], [ev[k] for k in ok]
-    w = rng.uniform(1, 3, size=len(eu))
+    w = rng.integers(1, 4, size=len(eu)).astype(float) if integer else rng.uniform(1, 3, size=len(eu))
     D = engine.apsp(C, eu, ev, w)
     assert np.isinf(D).any() == disconnected
     dc, dt, eng = engine.DeviceCircuit(ir, dev), engine.DistanceTable(D, dev), engine.Engine(dev)

@@ -103,7 +103,7 @@ def main():
             C = pick(2, 256)
             cap = pick(2, 10)
             Q = min(pick(2, 1024), C * cap)
-            return "gtrhqa_place", TP.test_gtrhqa_device_placement_matches_oracle, (Q, pick(1, 14), C, cap, pick(1, 4), bool(pick(0, 4) == 0 and C >= 6))
+            return "gtrhqa_place", TP.test_gtrhqa_device_placement_matches_oracle, (Q, pick(1, 14), C, cap, pick(1, 4), bool(pick(0, 4) == 0 and C >= 6), bool(pick(0, 1)))
         return "core_activity", TP.test_core_activity_and_comm_matrix_random, (wide_q() if pick(0, 1) else pick(2, 300), pick(1, 60), pick(2, 256), pick(1, 4))
 
     while time.time() - t0 < budget:
