@@ -21,6 +21,9 @@
 #ifndef QP_GT_WAVES
 #define QP_GT_WAVES 6
 #endif
+#ifndef QP_GT_WAVES_INT
+#define QP_GT_WAVES_INT 7
+#endif
 
 namespace {
 
@@ -114,8 +117,11 @@ __global__ void k_gtrhqa_prepare(const double* D, int C, double* Dz, uint16_t* D
 
 // kThreads = 1024: 16 waves share an instance's bidding (shortest time for one placement);
 // kThreads = 256: more instances resident per CU (highest throughput for large batches).
-template <int kThreads>
-__global__ __launch_bounds__(kThreads, kThreads == 256 ? QP_GT_WAVES : 4) void k_gtrhqa_place(GpArgs p) {
+// SMALLINT: the instantiation for tables of small integers (bids from the 16-bit copy).  Which kind a table
+// is, is known on the device only (k_gtrhqa_prepare's flag), so both instantiations are launched and the one
+// that does not apply returns at once; each is compiled for the registers its own bid loop needs.
+template <int kThreads, bool SMALLINT>
+__global__ __launch_bounds__(kThreads, kThreads == 256 ? (SMALLINT ? QP_GT_WAVES_INT : QP_GT_WAVES) : 4) void k_gtrhqa_place(GpArgs p) {
     constexpr int kWaves = kThreads / kWave;
     extern __shared__ __align__(16) uint8_t smem[];
     __shared__ int s_nops, s_nav, s_nleft, s_nfree, s_nneed, s_flag, s_wave_cnt[kWaves], s_base;
@@ -136,7 +142,7 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? QP_GT_WAVES : 4) void k
 
     // all distances finite: then every entry is, and the "nothing finite left" test never fires
     const bool dfinite = p.all_finite[0] != 0;
-    const bool dsmallint = p.all_finite[1] != 0;
+    if ((p.all_finite[1] != 0) != SMALLINT) return;  // uniform: the other instantiation does this table
 
 #ifdef QP_GTRHQA_TIMING
     long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
@@ -289,7 +295,7 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? QP_GT_WAVES : 4) void k
                         // The 32 loads of a lane's 16 columns are issued together, with no branch between them
                         // (columns past nav repeat the last one and are masked out by fmask): a step costs one
                         // memory latency, not one per column.
-                        if (dsmallint) {  // (uniform) integer table: 2-byte loads, 32-bit sums and compares
+                        if constexpr (SMALLINT) {  // integer table: 2-byte loads, 32-bit sums and compares
                             const char* hbase = reinterpret_cast<const char*>(p.D16);
                             const uint32_t h1 = r1 >> 2, h2 = r2 >> 2;
                             uint32_t s1[16], s2[16];
@@ -513,12 +519,15 @@ extern "C" int qp_gtrhqa_place(const QpCircuit* circ, const QpDTable* dt, const 
     int per_cu = 1;
     // few instances: give each one a whole 16-wave workgroup; many: small workgroups, more of them per CU
     const bool wide = B <= (int64_t)2 * cus;
-    void (*kern)(GpArgs) = wide ? k_gtrhqa_place<1024> : k_gtrhqa_place<256>;
     const int threads = wide ? 1024 : 256;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)off));
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), threads, off));
-    const unsigned grid = (unsigned)std::min<int64_t>(B, (int64_t)cus * std::max(per_cu, 1));
-    kern<<<grid, threads, off, stream>>>(p);
-    HIP_TRY(hipGetLastError());
+    void (*kerns[2])(GpArgs) = {wide ? k_gtrhqa_place<1024, false> : k_gtrhqa_place<256, false>,
+                                wide ? k_gtrhqa_place<1024, true> : k_gtrhqa_place<256, true>};
+    for (auto kern : kerns) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)off));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), threads, off));
+        const unsigned grid = (unsigned)std::min<int64_t>(B, (int64_t)cus * std::max(per_cu, 1));
+        kern<<<grid, threads, off, stream>>>(p);
+        HIP_TRY(hipGetLastError());
+    }
     return QP_OK;
 }
