@@ -187,6 +187,15 @@ int qp_dtable_grid_metric(const double* D_host, int32_t C, QpGridMetric* out);
  * from the source), a few units in the last place. */
 int qp_dtable_symmetric(const double* D_host, int32_t C, double rel_tol);
 
+/* HQA / TRHQA "make space" step for the listed instances of a batch (HQA_placer.py:180-204 ==
+ * TRHQA_placer.py's copy): in core order, every core that holds more than cap-2 qubits gives up to two of
+ * them (lowest qubit index first, as the row stands when the core's turn comes; stops as soon as the core
+ * is down to cap-2) to the core with room (fewer than cap-1 qubits) that is nearest by D[core][.], ties by
+ * lower occupancy, then lower core index.  a: host uint8 [.][lda] assignment rows, occ: host int64 [.][C]
+ * core occupancies, both updated in place for rows[0..n_rows); D: host double [C][C]. */
+int qp_make_space(uint8_t* a, int64_t* occ, const int64_t* rows, int64_t n_rows, int32_t Q, int32_t lda,
+                  int32_t C, int32_t cap, const double* D);
+
 /* ---------------------------------------------------------------- device: cost evaluation */
 
 /* Workspace (bytes, dev) qp_slice_cost_v3 / _v2 need for B partitions of circuit (T slices). */

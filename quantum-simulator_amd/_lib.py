@@ -79,6 +79,8 @@ EXPORTS = {
                                  C.POINTER(C.c_size_t)]),
     "qp_dtable_grid_metric": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(QpGridMetric)]),
     "qp_dtable_symmetric": (C.c_int, [C.c_void_p, C.c_int32, C.c_double]),
+    "qp_make_space": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                                C.c_int32, C.c_void_p]),
     "qp_slice_cost_workspace": (C.c_size_t, [C.c_int32, C.c_int64]),
     "qp_slice_cost_v3": (C.c_int, [C.POINTER(QpCircuit), C.POINTER(QpDTable), C.c_void_p, C.c_int64, C.c_int32,
                                    C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

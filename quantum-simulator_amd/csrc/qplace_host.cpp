@@ -328,6 +328,41 @@ extern "C" int qp_dtable_pack(const double* D, int32_t C, void* staging, size_t 
     return QP_OK;
 }
 
+extern "C" int qp_make_space(uint8_t* a, int64_t* occ, const int64_t* rows, int64_t n_rows, int32_t Q, int32_t lda,
+                             int32_t C, int32_t cap, const double* D) {
+    if (!a || !occ || (n_rows > 0 && !rows) || !D || n_rows < 0 || Q <= 0 || lda < Q || C <= 0 || C > 256)
+        return qp::fail(QP_EINVAL, "qp_make_space: bad arguments");
+    const int64_t lim = (int64_t)cap - 2;
+    for (int64_t k = 0; k < n_rows; ++k) {
+        if (rows[k] < 0) return qp::fail(QP_EINVAL, "qp_make_space: negative row index");
+        uint8_t* ar = a + (size_t)rows[k] * lda;
+        int64_t* oc = occ + (size_t)rows[k] * C;
+        for (int32_t core = 0; core < C; ++core) {
+            if (oc[core] <= lim) continue;
+            // the core's first two qubits as the row stands now (earlier cores may have sent it some)
+            int32_t inside[2], n_in = 0;
+            for (int32_t q = 0; q < Q && n_in < 2; ++q)
+                if (ar[q] == core) inside[n_in++] = q;
+            const double* drow = D + (size_t)core * C;
+            for (int32_t j = 0; j < n_in; ++j) {
+                int32_t best = -1;
+                for (int32_t tc = 0; tc < C; ++tc) {
+                    if (tc == core || oc[tc] >= (int64_t)cap - 1) continue;
+                    // strict comparisons keep the first of equal keys, as the reference's stable sort does
+                    if (best < 0 || drow[tc] < drow[best] || (drow[tc] == drow[best] && oc[tc] < oc[best])) best = tc;
+                }
+                if (best >= 0) {
+                    ar[inside[j]] = (uint8_t)best;
+                    --oc[core];
+                    ++oc[best];
+                }
+                if (oc[core] <= lim) break;
+            }
+        }
+    }
+    return QP_OK;
+}
+
 extern "C" int qp_dtable_symmetric(const double* D, int32_t C, double rel_tol) {
     if (!D || C <= 0 || !(rel_tol >= 0.0)) return qp::fail(QP_EINVAL, "qp_dtable_symmetric: bad arguments");
     for (int32_t a = 0; a < C; ++a) {

@@ -11,12 +11,13 @@ Nothing here computes a cost on the CPU in Python.
 from __future__ import annotations
 
 import random
+from bisect import insort
 from collections import deque
 
 import numpy as np
 
 from . import engine as E
-from ._lib import QP_ABSENT, QP_CM_GTRHQA, QP_CM_HQA, QP_CM_TRHQA, QP_V1, QP_V2, QP_V4
+from ._lib import QP_ABSENT, QP_CM_GTRHQA, QP_CM_HQA, QP_CM_TRHQA, QP_V1, QP_V2, QP_V4, check, lib, ptr
 from .multicore import graph_tables
 from .timeslices import CircuitIR, circuit_ir
 
@@ -352,8 +353,9 @@ class _HqaFamily(BasePlacer):
                 spent[live] += 1
                 room = occ <= cap - 2
                 has = room.any(1)
-                for b in np.flatnonzero(live & ~has):
-                    self._make_space(a[b], occ[b], cap, C, D)
+                stuck = np.flatnonzero(live & ~has)
+                if stuck.size:  # (a: uint8 [B, Q], occ: int64 [B, C], both contiguous; the native loop of _make_space)
+                    check(lib().qp_make_space(ptr(a), ptr(occ), ptr(stuck), stuck.size, Q, a.shape[1], C, cap, ptr(D)))
                 go = np.flatnonzero(live & has)
                 if go.size == 0:
                     continue
@@ -405,20 +407,36 @@ class _HqaFamily(BasePlacer):
     @staticmethod
     def _make_space(a, occ, cap, C, D):
         """HQA_placer.py:180-204: from every core above cap-2, move up to two of its qubits (lowest
-        qubit index first) to the nearest core with room, ties by lower occupancy then node order."""
+        qubit index first, as they stand when the core's turn comes) to the nearest core with room, ties
+        by lower occupancy then node order.  ``a`` and ``occ`` are updated in place; ``D`` may be the
+        matrix or its rows as lists.  Plain lists throughout: the per-core numpy calls of a vectorised
+        version cost more than the work at these sizes."""
+        lim = cap - 2
+        occl = occ.tolist()
+        if max(occl) <= lim:
+            return
+        members = [[] for _ in range(C)]
+        for q, c in enumerate(a.tolist()):
+            members[c].append(q)
         for core in range(C):
-            if occ[core] > cap - 2:
-                inside = np.flatnonzero(a == core)[:2]
-                for q in inside.tolist():
-                    cand = [(D[core, tc], occ[tc], tc) for tc in range(C) if occ[tc] < cap - 1 and tc != core]
-                    if cand:
-                        cand.sort(key=lambda x: (x[0], x[1]))
-                        tc = cand[0][2]
-                        a[q] = tc
-                        occ[core] -= 1
-                        occ[tc] += 1
-                    if occ[core] <= cap - 2:
+            if occl[core] > lim:
+                drow = D[core] if isinstance(D, list) else D[core].tolist()
+                for q in members[core][:2]:
+                    best, bkey = -1, None
+                    for tc in range(C):
+                        if occl[tc] < cap - 1 and tc != core:
+                            key = (drow[tc], occl[tc])
+                            if bkey is None or key < bkey:  # strict: the first of equal keys, as a stable sort gives
+                                best, bkey = tc, key
+                    if best >= 0:
+                        a[q] = best
+                        members[core].remove(q)
+                        insort(members[best], q)
+                        occl[core] -= 1
+                        occl[best] += 1
+                    if occl[core] <= lim:
                         break
+        occ[:] = occl
 
 
 class hqa_placer(_HqaFamily):

@@ -357,3 +357,34 @@ def test_dtable_symmetric():
     ev = [(i + 1) % 30 for i in range(30)] + [15, 20, 27]
     D = apsp(30, eu, ev, rng.uniform(1, 3, size=len(eu)))
     assert L.qp_dtable_symmetric(_lib.ptr(D), 30, 1e-13) == 1
+
+
+def test_make_space_native_equals_python():
+    """qp_make_space (the batch loop of HQA / TRHQA placements) against placers._HqaFamily._make_space, which
+    the single-instance path uses and the reference fixtures pin: random over-full assignments, ties in
+    distance and occupancy (integer distances), rows that need nothing."""
+    from quantum_simulator_amd.placers import hqa_placer
+    L = _lib.lib()
+    rng = np.random.default_rng(12)
+    for trial in range(200):
+        C = int(rng.integers(2, 40))
+        cap = int(rng.integers(2, 7))
+        Q = int(rng.integers(1, C * cap + 1))
+        lda = Q + int(rng.integers(0, 5))
+        n = int(rng.integers(1, 6))
+        D = rng.integers(1, 5, size=(C, C)).astype(np.float64) if trial % 2 else rng.uniform(1, 9, size=(C, C))
+        np.fill_diagonal(D, 0.0)
+        a = np.zeros((n, lda), np.uint8)
+        for r in range(n):  # any assignment within capacity; crowded ones are what the step is for
+            slots = np.repeat(np.arange(C), cap)
+            a[r, :Q] = rng.permutation(slots)[:Q] if r % 2 else np.sort(rng.permutation(slots)[:Q])
+        occ = np.stack([np.bincount(a[r, :Q], minlength=C) for r in range(n)]).astype(np.int64)
+        rows = np.flatnonzero(rng.random(n) < 0.7).astype(np.int64)
+        want_a, want_occ = a.copy(), occ.copy()
+        for r in rows:
+            hqa_placer._make_space(want_a[r, :Q], want_occ[r], cap, C, D)
+        got_a, got_occ = a.copy(), occ.copy()
+        assert L.qp_make_space(_lib.ptr(got_a), _lib.ptr(got_occ), _lib.ptr(rows) if rows.size else None, rows.size,
+                               Q, lda, C, cap, _lib.ptr(D)) == 0
+        assert (got_a == want_a).all() and (got_occ == want_occ).all(), trial
+    assert L.qp_make_space(None, None, None, 0, 1, 1, 1, 2, None) < 0
