@@ -113,6 +113,14 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it first (python -c 'import __graft_entry__ as g; g.build()'). "
                 "This package has no CPU fallback.")
+        # torch first: its wheel brings its own copy of the HIP runtime, and whichever copy is loaded first
+        # is the one both end up using.  If this library's system copy came first (host helpers called before
+        # anything touched torch), torch would later load a second runtime and device calls from here would
+        # fail with "no ROCm-capable device is detected".
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in EXPORTS.items():
             fn = getattr(L, name)  # AttributeError if the symbol is not exported
