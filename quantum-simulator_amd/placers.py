@@ -550,13 +550,14 @@ class random_placer(_SparsePlacer):
             for cmd in layer:
                 members.update(cmd.qubits)
             placed = {}
-            for q in list(members):
-                if q not in placed:
-                    open_nodes = [n for n in nodes if room[n] > 0]
-                    if open_nodes:
-                        n = random.choice(open_nodes)
-                        placed[q] = n
-                        room[n] -= 1
+            open_nodes = [n for n in nodes if room[n] > 0]  # (the reference rebuilds this list per qubit; it only
+            for q in list(members):                         # changes when a core fills up)
+                if q not in placed and open_nodes:
+                    n = random.choice(open_nodes)
+                    placed[q] = n
+                    room[n] -= 1
+                    if room[n] == 0:
+                        open_nodes = [m for m in nodes if room[m] > 0]
             for n in nodes:
                 net.nodes[n]["qpu"].available_qubits = room[n]
             result.append(placed)
