@@ -831,40 +831,226 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_grid_row(V3Args p) {
     }
 }
 
-// Any row pitch: one 256-thread workgroup per item, everything gathered from global memory.
-template <int KIND>
-__global__ __launch_bounds__(256) void k_cost_v3_wide(V3Args p) {
+// Rows longer than 1024 bytes.  One workgroup of 16 waves owns an item.  Its threads form 1024 / P groups
+// (P = pieces of 16 bytes per row, rounded up to a power of two, at most 1024); a group takes a run of the
+// item's rows, thread j of it owns pieces j, j + 1024, ... (NP of them: 1 for rows up to 16 KB, kWidePieces
+// for rows up to 64 KB) and carries the previous row's pieces in registers, so rows are read once, 16 bytes
+// per lane, with the loads of the next AHEAD rows in flight.  Only qubits that moved are looked up; under a
+// grid metric nothing is (packed coordinate differences, as in the 1 KB kernel).  The groups step through
+// their runs together: each parks its row in an LDS strip, the workgroup meets at a barrier, and the group's
+// threads gather the endpoints of the row's gates from the strip (byte gathers from device memory run at
+// one address per clock per CU and were 4x slower than the row stream).  NBUF = 2 strips per group alternate,
+// one barrier per step; NBUF = 1 needs a second barrier.  Every load a step consumes was issued at least one
+// step earlier and nothing is loaded under a branch, so the waits the compiler counts leave the younger
+// loads in flight: rows AHEAD steps ahead together with their slice bounds, the first 8 gate words of a
+// thread (two 16-byte loads from the padded gate list) AHEAD / 2 steps ahead.  Without the padded gate list
+// the gates come from the edge records, loaded where they are used (slower, same sums up to their order).
+// TABMODE: kTabLdsC (table staged in LDS at pitch C), kTabGlobal, kTabGrid.
+constexpr int kWidePieces = 4;
+constexpr int kWideGateLoads = 2;  // 16-byte loads of gate words per thread and row that are prefetched
+
+template <int KIND, int TABMODE, int NP, int NBUF>
+__global__ __launch_bounds__(kV3Threads) void k_cost_v3_wide(V3Args p) {
+    extern __shared__ __align__(16) uint8_t smem[];
     using E = typename Tab<KIND>::elem;
-    __shared__ double red[256 / kWave];
-    const E* tab = static_cast<const E*>(p.table);
-    const uint32_t last = (uint32_t)p.C * (uint32_t)p.C - 1u;  // a core id >= C (caller's error) must not read past the table
+    using Acc = typename Tab<KIND>::acc;
+    constexpr int AHEAD = NP == 1 ? 4 : 2;
+    constexpr int GA = AHEAD / 2;
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    uint32_t tab_off = 0;
+    const E* tab = static_cast<const E*>(p.table);
+    if constexpr (TABMODE == kTabLdsC) {
+        tab_off = stage_table(smem, p.table, p.table_bytes);
+        tab = reinterpret_cast<const E*>(smem);
+    }
+    uint8_t* strips = smem + tab_off;
+    double* red = reinterpret_cast<double*>(strips);  // the per-wave sums of an item reuse the strips' first bytes
+    const uint32_t C = (uint32_t)p.C, last = C * C - 1u;  // a core id >= C (caller's error) never reads past a table
+    auto pair_at = [&](uint32_t from, uint32_t to) -> Acc { return (Acc)tab[min(from * C + to, last)]; };
+    const int npieces = p.ldq / 16;
+    int P = 128;  // rows here have more than 64 pieces, so a group is made of whole waves
+    while (P < npieces && P < kV3Threads) P *= 2;
+    const int groups = kV3Threads / P, tin = threadIdx.x % P;
+    const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x / P);
+    const int strip_bytes = P * 16 * NP;
+    // the padded gate list, or (without one) any readable 16 bytes whose contents are ignored
+    const bool sched = p.edges_sched != nullptr && p.sptr != nullptr;
+    const uint32_t* gsrc = sched ? p.edges_sched : reinterpret_cast<const uint32_t*>(p.A);
+    const int32_t* bsrc = sched ? p.sptr : p.sep;
+    const int sched_end = sched ? p.sptr[p.T] : 0;  // zero words follow the last slice
+    // bytes of qubits that do not exist are zeroed in every piece (keep[k][w]: dword w of piece k); a thread
+    // without a k-th piece re-reads piece 0, masks all of it and writes nothing to the strip
+    uint32_t keep[NP][4];
+    int off[NP];
+    bool have[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int piece = tin + k * kV3Threads;
+        have[k] = piece < npieces;
+        off[k] = have[k] ? piece * 16 : 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int nb = have[k] ? min(4, max(0, p.Q - (piece * 16 + 4 * w))) : 0;
+            keep[k][w] = nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u);
+        }
+    }
     for (int64_t it = blockIdx.x; it < p.nitems; it += gridDim.x) {
         const int chunk = (int)(it / p.B);
         const int64_t b = it - (int64_t)chunk * p.B;
         const int r0 = chunk * p.rows_per_item;
         const int r1 = min(p.T, r0 + p.rows_per_item);
         const uint8_t* base = p.A + (size_t)b * p.Tp * p.ldq;
-        double acc = 0.0;
-        for (int row = max(r0, 2); row < r1; ++row) {
-            const uint8_t* cr = base + (size_t)row * p.ldq;
-            const uint8_t* pr = cr - p.ldq;
-            for (int q = threadIdx.x; q < p.Q; q += blockDim.x) acc += (double)tab[min((uint32_t)pr[q] * p.C + cr[q], last)];
+        Acc acc = 0;
+        GridAcc gacc;
+        // this group's run of rows; runs differ by at most one row, every group takes nsteps steps
+        const int g0 = r0 + (int)((int64_t)(r1 - r0) * grp / groups), g1 = r0 + (int)((int64_t)(r1 - r0) * (grp + 1) / groups);
+        const int nsteps = (r1 - r0 + groups - 1) / groups;
+        auto fetch = [&](int row, int k) -> uint4 { return load_row16(base + (size_t)min(row, r1 - 1) * p.ldq + off[k]); };
+        auto fetch_bounds = [&](int row) -> int2 {
+            const int32_t* bp = bsrc + min(row, r1 - 1);
+            return make_int2(bp[0], bp[1]);
+        };
+        auto fetch_gates = [&](int slice_start, int j) -> uint4 {  // words 4 * (tin + j * P) .. + 3 of a slice
+            const int w = sched ? min(slice_start + 4 * (tin + j * P), sched_end) : 0;
+            return *reinterpret_cast<const uint4*>(gsrc + w);
+        };
+        auto gate_cost = [&](uint32_t u, uint32_t v) {
+            if constexpr (TABMODE == kTabGrid) gacc.add4(p, u, v);
+            else if (u != v) acc += pair_at(u, v);
+        };
+        uint32_t prev[NP][4];
+        uint4 ring[AHEAD][NP];
+        int2 bring[AHEAD];
+        uint4 gring[GA][kWideGateLoads];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const uint4 v = g0 >= 1 ? fetch(g0 - 1, k) : make_uint4(0, 0, 0, 0);
+            prev[k][0] = v.x & keep[k][0];
+            prev[k][1] = v.y & keep[k][1];
+            prev[k][2] = v.z & keep[k][2];
+            prev[k][3] = v.w & keep[k][3];
         }
-        for (int e = p.sep[r0] + threadIdx.x; e < p.sep[r1]; e += blockDim.x) {
-            const QpEdge ed = p.edges[e];
-            const uint8_t* cr = base + (size_t)ed.t * p.ldq;
-            acc += (double)tab[min((uint32_t)cr[ed.u] * p.C + cr[ed.v], last)];
+#pragma unroll
+        for (int a = 0; a < AHEAD; ++a) bring[a] = fetch_bounds(g0 + a);
+#pragma unroll
+        for (int a = 0; a < AHEAD; ++a)
+#pragma unroll
+            for (int k = 0; k < NP; ++k) ring[a][k] = fetch(g0 + a, k);
+#pragma unroll
+        for (int a = 0; a < GA; ++a)
+#pragma unroll
+            for (int j = 0; j < kWideGateLoads; ++j) gring[a][j] = fetch_gates(bring[a].x, j);
+        for (int s0 = 0; s0 < nsteps; s0 += AHEAD) {
+#pragma unroll
+            for (int a = 0; a < AHEAD; ++a) {
+                // no early exit from the unrolled steps (the register copies where such paths meet would wait
+                // for loads just issued): a step past the last one loads clamped addresses and does nothing else
+                const int step = s0 + a;
+                const int row = g0 + step;
+                const bool active = row < g1;
+                uint8_t* strip = strips + ((step & (NBUF - 1)) * groups + grp) * strip_bytes;
+                const int sb = bring[a].x, se = bring[a].y;
+                const int nw = active && sched ? se - sb : 0;  // gate words of this row
+                uint32_t cur[NP][4];
+#pragma unroll
+                for (int k = 0; k < NP; ++k) {
+                    cur[k][0] = ring[a][k].x & keep[k][0];
+                    cur[k][1] = ring[a][k].y & keep[k][1];
+                    cur[k][2] = ring[a][k].z & keep[k][2];
+                    cur[k][3] = ring[a][k].w & keep[k][3];
+                }
+                uint4 gw[kWideGateLoads];
+#pragma unroll
+                for (int j = 0; j < kWideGateLoads; ++j) {
+                    gw[j] = gring[a % GA][j];
+                    gring[a % GA][j] = fetch_gates(bring[(a + GA) % AHEAD].x, j);  // gates of row + GA
+                }
+#pragma unroll
+                for (int k = 0; k < NP; ++k) ring[a][k] = fetch(row + AHEAD, k);
+                bring[a] = fetch_bounds(row + AHEAD);
+#pragma unroll
+                for (int k = 0; k < NP; ++k)
+                    if (active && have[k]) *reinterpret_cast<uint4*>(strip + off[k]) = make_uint4(cur[k][0], cur[k][1], cur[k][2], cur[k][3]);
+                if (active && row >= 2) {  // movement is charged from row 2 on
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) {
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) {
+                            const uint32_t pf = prev[k][w], cf = cur[k][w];
+                            if constexpr (TABMODE == kTabGrid) {
+                                gacc.add4(p, pf, cf);
+                            } else if (pf != cf) {
+                                if constexpr (TABMODE == kTabGlobal) {  // a look-up is an L2 gather: only for qubits that moved
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) {
+                                        const uint32_t f = (pf >> (8 * j)) & 0xFFu, c = (cf >> (8 * j)) & 0xFFu;
+                                        if (f != c) acc += pair_at(f, c);
+                                    }
+                                } else {  // the table's diagonal is zero: the four look-ups of a dword go out together
+                                    Acc d4[4];
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) d4[j] = pair_at((pf >> (8 * j)) & 0xFFu, (cf >> (8 * j)) & 0xFFu);
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) acc += d4[j];
+                                }
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < NP; ++k)
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) prev[k][w] = cur[k][w];
+                __syncthreads();  // the rows of this step are in their strips
+                if (4 * tin < nw) {
+#pragma unroll
+                    for (int j = 0; j < kWideGateLoads; ++j) {
+                        if (j > 0 && 4 * (tin + j * P) >= nw) continue;  // most rows have fewer than 4 * P gates
+                        const uint32_t g4[4] = {gw[j].x, gw[j].y, gw[j].z, gw[j].w};
+                        uint32_t au[4], av[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            // a word past the slice's end belongs to a later slice: qubit 0 with itself instead
+                            const uint32_t g = 4 * (tin + j * P) + c < nw ? g4[c] : 0u;
+                            au[c] = strip[g & 0xFFFFu];
+                            av[c] = strip[g >> 16];
+                        }
+                        if constexpr (TABMODE == kTabGrid) {
+                            gacc.add4(p, au[0] | au[1] << 8 | au[2] << 16 | au[3] << 24, av[0] | av[1] << 8 | av[2] << 16 | av[3] << 24);
+                        } else {
+                            Acc d4[4];
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) d4[c] = pair_at(au[c], av[c]);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) acc += d4[c];
+                        }
+                    }
+                    for (int w = 4 * kWideGateLoads * P + tin; w < nw; w += P) {  // rows with more than 8 * P gates
+                        const uint32_t g = gsrc[sb + w];
+                        gate_cost(strip[g & 0xFFFFu], strip[g >> 16]);
+                    }
+                }
+                if (!sched && active) {
+                    for (int e = sb + tin; e < se; e += P) {
+                        const QpEdge ed = p.edges[e];
+                        gate_cost(strip[ed.u], strip[ed.v]);
+                    }
+                }
+                if constexpr (NBUF == 1) __syncthreads();  // the one strip is free again
+            }
         }
-        acc = wave_sum(acc);
-        __syncthreads();
-        if (lane == 0) red[wave] = acc;
+        double s;
+        if constexpr (TABMODE == kTabGrid) s = gacc.total(p);
+        else s = wave_sum(acc);
+        __syncthreads();  // nobody reads a strip any more
+        if (lane == 0) red[wave] = s;
         __syncthreads();
         if (threadIdx.x == 0) {
-            double s = 0.0;
-            for (int w = 0; w < 256 / kWave; ++w) s += red[w];
-            p.partial[it] = s;
+            double tot = 0.0;
+            for (int w = 0; w < kV3Waves; ++w) tot += red[w];
+            p.partial[it] = tot;
         }
+        __syncthreads();  // the sums are read before the next item's rows overwrite them
     }
 }
 
@@ -1144,6 +1330,24 @@ __global__ __launch_bounds__(256) void k_cost_matrix(CmArgs p) {
 // launch helpers
 // ------------------------------------------------------------------------------------------------
 
+// Byte-replicated masks and weights of a grid metric, as the closed-form kernels take them.
+int fill_grid_args(V3Args& p, const QpDTable* dt) {
+    const QpGridMetric& g = dt->grid;
+    if (g.xbits < 0 || g.xbits > 8 || (g.wrap_x && g.wrap_x != (1 << g.xbits)) || g.wrap_x > 128 ||
+        g.wrap_y > 128 || (g.wrap_y & (g.wrap_y - 1)) || (g.wrap_y && (g.wrap_y << g.xbits) != dt->C))
+        return qp::fail(QP_EINVAL, "qp_slice_cost_v3: inconsistent grid metric");
+    const uint32_t rep = 0x01010101u;
+    p.gxb = (uint32_t)g.xbits;
+    p.gxm = ((1u << g.xbits) - 1u) * rep;
+    p.gym = (g.wrap_y ? (uint32_t)(g.wrap_y - 1) : (0xFFu >> g.xbits)) * rep;
+    p.ghalfx = (uint32_t)(g.wrap_x / 2) * rep;
+    p.ghalfy = (uint32_t)(g.wrap_y / 2) * rep;
+    p.gwx = g.wx;
+    p.gwy = g.wy;
+    p.gyi = p.gym << p.gxb;
+    return QP_OK;
+}
+
 int rows_per_item_for(int32_t T, int32_t G, int64_t B, int cus) {
     if (G == 1) {
         // one row per step: long items amortise the pipeline fill at an item's start (the first rows are
@@ -1219,6 +1423,13 @@ extern "C" int qp_slice_cost_v3(const QpCircuit* circ, const QpDTable* dt, const
     }
     const int cus = qp::device_cus();
     p.rows_per_item = rows_per_item_for(T, p.G, B, cus);
+    if (!narrow) {
+        // the wide kernel splits an item's rows over 1024 / P thread groups (P as the kernel forms it): runs
+        // of at least 32 rows per group, so a run's start-up (one extra row, the first loads waited for) is small
+        int P = 64;
+        while (P < ldq / 16 && P < kV3Threads) P *= 2;
+        p.rows_per_item = std::min<int>(T, std::max(p.rows_per_item, 32 * (kV3Threads / P)));
+    }
     const int32_t nchunks = (T + p.rows_per_item - 1) / p.rows_per_item;
     p.nitems = (int64_t)nchunks * B;
     if (!workspace || workspace_bytes < (size_t)p.nitems * sizeof(double))
@@ -1243,19 +1454,8 @@ extern "C" int qp_slice_cost_v3(const QpCircuit* circ, const QpDTable* dt, const
         void (*kern)(V3Args) = nullptr;
         if (gridpath) {
             // closed-form distances: no table in LDS, so more than one workgroup fits a CU
+            if (int rc = fill_grid_args(p, dt)) return rc;
             const QpGridMetric& g = dt->grid;
-            if (g.xbits < 0 || g.xbits > 8 || (g.wrap_x && g.wrap_x != (1 << g.xbits)) || g.wrap_x > 128 ||
-                g.wrap_y > 128 || (g.wrap_y & (g.wrap_y - 1)) || (g.wrap_y && (g.wrap_y << g.xbits) != dt->C))
-                return qp::fail(QP_EINVAL, "qp_slice_cost_v3: inconsistent grid metric");
-            const uint32_t rep = 0x01010101u;
-            p.gxb = (uint32_t)g.xbits;
-            p.gxm = ((1u << g.xbits) - 1u) * rep;
-            p.gym = (g.wrap_y ? (uint32_t)(g.wrap_y - 1) : (0xFFu >> g.xbits)) * rep;
-            p.ghalfx = (uint32_t)(g.wrap_x / 2) * rep;
-            p.ghalfy = (uint32_t)(g.wrap_y / 2) * rep;
-            p.gwx = g.wx;
-            p.gwy = g.wy;
-            p.gyi = p.gym << p.gxb;
             const bool wrap = g.wrap_x || g.wrap_y;
             if (!rowpath) kern = k_cost_v3<QP_DT_U16, kTabGrid>;
             else kern = wrap ? k_cost_v3_grid_row<true, kV3Ahead> : k_cost_v3_grid_row<false, kV3Ahead>;
@@ -1335,9 +1535,32 @@ extern "C" int qp_slice_cost_v3(const QpCircuit* circ, const QpDTable* dt, const
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         kern<<<grid, kV3Threads, lds, stream>>>(p);
     } else {
-        const unsigned grid = (unsigned)std::min<int64_t>((int64_t)cus * 8, p.nitems);
-        if (dt->kind == QP_DT_F64) k_cost_v3_wide<QP_DT_F64><<<grid, 256, 0, stream>>>(p);
-        else k_cost_v3_wide<QP_DT_U16><<<grid, 256, 0, stream>>>(p);
+        if (ldq / 16 > kWidePieces * kV3Threads) return qp::fail(QP_EINVAL, "qp_slice_cost_v3: rows longer than 65536 bytes");
+        const bool gridpath = dt->kind == QP_DT_U16 && dt->grid.valid;
+        // LDS: the table (if it fits beside one set of strips) and one or two strips of a row per group
+        const bool one = ldq / 16 <= kV3Threads;  // one piece per thread
+        const size_t strip_set = (size_t)kV3Threads * 16 * (one ? 1 : kWidePieces);
+        const bool tab_lds = !gridpath && tab_padded + strip_set <= (size_t)kLdsBytes;
+        const bool two = (tab_lds ? tab_padded : 0) + 2 * strip_set <= (size_t)kLdsBytes;
+        void (*kern)(V3Args) = nullptr;
+#define QP_WIDE(KIND, MODE) \
+    (one ? (two ? k_cost_v3_wide<KIND, MODE, 1, 2> : k_cost_v3_wide<KIND, MODE, 1, 1>) \
+         : (two ? k_cost_v3_wide<KIND, MODE, kWidePieces, 2> : k_cost_v3_wide<KIND, MODE, kWidePieces, 1>))
+        if (gridpath) {
+            if (int rc = fill_grid_args(p, dt)) return rc;
+            kern = QP_WIDE(QP_DT_U16, kTabGrid);
+        } else if (dt->kind == QP_DT_F64) {
+            kern = tab_lds ? QP_WIDE(QP_DT_F64, kTabLdsC) : QP_WIDE(QP_DT_F64, kTabGlobal);
+        } else {
+            kern = tab_lds ? QP_WIDE(QP_DT_U16, kTabLdsC) : QP_WIDE(QP_DT_U16, kTabGlobal);
+        }
+#undef QP_WIDE
+        const size_t lds = (tab_lds ? tab_padded : 0) + (two ? 2 : 1) * strip_set;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int per_cu = 1;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), kV3Threads, lds));
+        const unsigned grid = (unsigned)std::min<int64_t>((int64_t)cus * std::max(per_cu, 1), p.nitems);
+        kern<<<grid, kV3Threads, lds, stream>>>(p);
     }
     HIP_TRY(hipGetLastError());
     k_sum_chunks<<<(unsigned)((B + 255) / 256), 256, 0, stream>>>(p.partial, B, nchunks, out);

@@ -381,6 +381,65 @@ def test_cost_v3_full_size_against_c_oracle(gpu, integer):
     assert got.tobytes() == eng.cost_v3(dc, dt, torch.from_numpy(A).to(dev)).cpu().numpy().tobytes()
 
 
+WIDE = [  # Q, T, topology, nx, ny, integer weight (0 = uniform(1,3)), B, share of qubits that move per row
+    (2048, 70, "mesh", 4, 4, 2.0, 3, 0.1),       # closed form and uint16 table in LDS
+    (1100, 300, "mesh", 16, 16, 0, 2, 0.05),     # fp64 table of 256 cores stays in device memory; two chunks
+    (3000, 20, "torus", 8, 8, 1.0, 2, 1.0),      # rings; every qubit moves
+    (1500, 33, "star", 9, 1, 0, 2, 0.3),         # fp64 table in LDS, pieces not a power of two
+    (4099, 9, "mesh", 4, 3, 3.0, 2, 0.5),        # integer table without a closed form
+    (20000, 7, "mesh", 4, 4, 2.0, 2, 0.2),       # four pieces per thread
+    (30001, 4, "line", 7, 1, 0, 2, 0.2),
+    (32767, 3, "mesh", 16, 16, 0, 1, 0.02),      # the longest row the circuit tables allow
+]
+
+
+@pytest.mark.parametrize("Q,T,topo,nx,ny,wt,B,pmove", WIDE)
+def test_cost_v3_wide_rows(gpu, Q, T, topo, nx, ny, wt, B, pmove):
+    """Rows longer than 1024 bytes (a workgroup per item, groups of threads per run of rows) against the C
+    restatement: exact for integer tables, closed form == table look-ups bit for bit."""
+    torch, engine, eng, dev = gpu
+    import random
+    from oracle import c_oracle
+    from quantum_simulator_amd import layered_gate_arrays
+    from quantum_simulator_amd.multicore import multicore
+    from quantum_simulator_amd.timeslices import CircuitIR
+    random.seed(Q)
+    arch = multicore(nx, ny, ncp_qubits=4, edge_weight_range=(wt, wt) if wt else (1.0, 3.0), network_type=topo)
+    dt = engine.DistanceTable.from_network(arch.network, dev)
+    assert (dt.kind == engine.QP_DT_U16) == bool(wt)
+    C = dt.C
+    rng = np.random.default_rng(Q + T)
+    q0, q1, _ = layered_gate_arrays(Q, T, 0.6, seed=Q + C)
+    keep = rng.random(len(q0)) > 0.25
+    ir = CircuitIR.from_gate_tables(Q, q0[keep], q1[keep])
+    dc = engine.DeviceCircuit(ir, dev)
+    assert dc.ldq > 1024
+    A = np.empty((B, ir.T, dc.ldq), np.uint8)
+    A[:, 0] = rng.integers(0, C, size=(B, dc.ldq), dtype=np.uint8)
+    for t in range(1, ir.T):
+        move = rng.random((B, dc.ldq)) < pmove
+        A[:, t] = np.where(move, rng.integers(0, C, size=(B, dc.ldq), dtype=np.uint8), A[:, t - 1])
+    A[:, :, Q:] = rng.integers(0, 256, size=(B, ir.T, dc.ldq - Q), dtype=np.uint8)  # pad bytes are garbage
+    Ad = torch.from_numpy(A).to(dev)
+    got = eng.cost_v3(dc, dt, Ad).cpu().numpy()
+    if wt:
+        assert got.tobytes() == eng.cost_v3(dc, dt, Ad, table="table").cpu().numpy().tobytes()
+    assert got.tobytes() == eng.cost_v3(dc, dt, Ad).cpu().numpy().tobytes()
+    # a caller that passes no padded gate list: the gates come from the edge records (another order of terms)
+    saved = dc.c.edges_sched, dc.c.sched_ptr
+    dc.c.edges_sched, dc.c.sched_ptr = None, None
+    try:
+        plain = eng.cost_v3(dc, dt, Ad).cpu().numpy()
+    finally:
+        dc.c.edges_sched, dc.c.sched_ptr = saved
+    assert all(_close(plain[b], got[b], bool(wt)) for b in range(B)), (plain, got)
+    gt = c_oracle.GateTables(ir.slices, ir.gate_q, ir.gate_mr)
+    nterms = ir.nE + ir.T * Q
+    for b in range(B):
+        want = c_oracle.cost_v3(gt, Q, A[b, :, :Q], dt.D)
+        assert _close(got[b], want, bool(wt), nterms), (b, got[b], want)
+
+
 def test_degenerate_circuits(gpu):
     """No gates at all (zero slices) and one-qubit gates only (slices without counted gates): what the
     reference's loops do with them — nothing, or movement only."""
