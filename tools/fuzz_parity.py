@@ -78,6 +78,7 @@ def main():
     gpu = (torch, engine, engine.Engine(dev), dev)
     t0 = time.time()
     runs, fails = {}, 0
+    last = [t0]
 
     def pick(lo, hi):
         return int(rng.integers(lo, hi + 1))
@@ -86,7 +87,14 @@ def main():
         return [pick(2, 80), pick(81, 512), pick(513, 1024), pick(1025, 1600)][pick(0, 3)]
 
     def draw():
-        kind = pick(0, 5)
+        kind = pick(0, 6)
+        if kind == 6:  # rows longer than 1 KB: one or four 16-byte pieces per thread, one or several chunks of rows
+            Q = pick(16385, 24000) if pick(0, 5) == 0 else pick(1025, 6000)
+            T = pick(1, max(1, min(600, 1200000 // Q)))
+            topo, nx, ny = [("mesh", pick(1, 16), pick(1, 16)), ("torus", pick(3, 16), pick(3, 16)), ("line", pick(2, 200), 1),
+                            ("star", pick(3, 60), 1), ("all_to_all", pick(2, 6), pick(1, 6))][pick(0, 4)]
+            wt = float(pick(1, 5)) if pick(0, 1) else 0
+            return "cost_v3_wide_rows", TC.test_cost_v3_wide_rows, (gpu, Q, T, topo, nx, ny, wt, pick(1, 3), float(rng.choice([0.02, 0.3, 1.0])))
         if kind == 5:
             C = pick(2, 256)
             cap = pick(2, 8)
@@ -113,6 +121,9 @@ def main():
             c0 = time.time()
             unwrap(fn)(*args)
             runs[name] = runs.get(name, 0) + 1
+            if time.time() - last[0] > 30:  # a line every half minute: a silent run is taken for a hung one
+                last[0] = time.time()
+                print(f"... {sum(runs.values())} cases after {time.time() - t0:.0f} s", flush=True)
             if os.environ.get("QP_FUZZ_VERBOSE"):
                 print(f"ok {name}{shown} {time.time() - c0:.3f} s", flush=True)
         except BaseException as e:  # AssertionError and anything a launch raises
