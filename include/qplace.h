@@ -196,6 +196,26 @@ int qp_dtable_symmetric(const double* D_host, int32_t C, double rel_tol);
 int qp_make_space(uint8_t* a, int64_t* occ, const int64_t* rows, int64_t n_rows, int32_t Q, int32_t lda,
                   int32_t C, int32_t cap, const double* D);
 
+/* n_rep placements by the RANDOM placer (Random_placer.py:25-59: per slice every active qubit draws
+ * random.choice over the cores that still have room) or the BFS placer (BFS_placer.py:101-200: two-qubit gates to
+ * the first core with two free slots, else to the closest pair of neighbouring cores with one free slot each;
+ * one-qubit gates draw random.choice; the rest is spread breadth-first from the emptiest cores, BFS_placer.py:7-18
+ * ordering the neighbours), consuming Python's random stream exactly as those loops do.
+ * member_ptr [T+1] / members: the active qubits of every slice in the order the reference iterates its set of them;
+ * cmd_ptr [T+1] / cmd_q0 / cmd_q1 (BFS): the commands of every slice in slice order, q1 = -1 for a one-qubit
+ * command, q0 = -1 for a command of any other arity; nb_ptr [C+1] / nb (BFS): the neighbours of every core,
+ * nearest first; D (BFS): host double [C][C].  Cores are numbered in the order of network.nodes().
+ * mt_states: host uint32 [n_states][625], each the 624 words and the position of a Mersenne Twister as
+ * random.getstate()[1] lists them, advanced in place; n_states = 1 (one stream through all repeats, as a loop of
+ * calls would use it) or n_rep (repeat r draws from state r).
+ * A_out: host uint8 [n_rep][T][ldq], QP_ABSENT where a qubit is not in the slice's dict, 0 in the padding. */
+#define QP_PLACE_RANDOM 0
+#define QP_PLACE_BFS 1
+int qp_place_sparse(int32_t which, int32_t T, int32_t Q, int32_t ldq, int32_t C, int32_t cap,
+                    const int32_t* member_ptr, const uint16_t* members, const int32_t* cmd_ptr,
+                    const int32_t* cmd_q0, const int32_t* cmd_q1, const int32_t* nb_ptr, const int32_t* nb,
+                    const double* D, uint32_t* mt_states, int32_t n_states, int32_t n_rep, uint8_t* A_out);
+
 /* ---------------------------------------------------------------- device: cost evaluation */
 
 /* Workspace (bytes, dev) qp_slice_cost_v3 / _v2 need for B partitions of circuit (T slices). */

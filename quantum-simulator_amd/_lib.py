@@ -15,6 +15,7 @@ QP_DT_F64, QP_DT_U16 = 0, 1
 QP_V2, QP_V1, QP_V4 = 0, 1, 2
 QP_CM_HQA, QP_CM_TRHQA, QP_CM_GTRHQA = 0, 1, 2
 QP_ABSENT = 0xFF
+QP_PLACE_RANDOM, QP_PLACE_BFS = 0, 1
 QP_SCHED_CHUNK, QP_SCHED_TAIL = 64, 512
 
 
@@ -81,6 +82,9 @@ EXPORTS = {
     "qp_dtable_symmetric": (C.c_int, [C.c_void_p, C.c_int32, C.c_double]),
     "qp_make_space": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                 C.c_int32, C.c_void_p]),
+    "qp_place_sparse": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_int32, C.c_int32, C.c_void_p]),
     "qp_slice_cost_workspace": (C.c_size_t, [C.c_int32, C.c_int64]),
     "qp_slice_cost_v3": (C.c_int, [C.POINTER(QpCircuit), C.POINTER(QpDTable), C.c_void_p, C.c_int64, C.c_int32,
                                    C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

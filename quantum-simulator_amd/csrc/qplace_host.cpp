@@ -702,3 +702,168 @@ extern "C" int qp_qasm_scan(const char* text, int64_t n, int64_t start, int32_t 
     *stop_out = i;
     return QP_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// RANDOM and BFS placements (Random_placer.py:25-59, BFS_placer.py:101-200): sequential per slice and
+// driven by Python's global random stream.  The stream is a Mersenne Twister whose 624 words + position
+// the caller hands over (random.getstate()) and takes back (random.setstate()); random.choice(seq) is
+// seq[randbelow(len(seq))] with randbelow(n) = the top bit_length(n) bits of the next 32-bit output,
+// redrawn until below n.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct PyRandom {
+    uint32_t* s;  // [625]: words, then the position
+    explicit PyRandom(uint32_t* state) : s(state) {}
+    uint32_t next32() {
+        constexpr int N = 624, M = 397;
+        uint32_t pos = s[N];
+        if (pos >= (uint32_t)N) {
+            auto mix = [](uint32_t u, uint32_t v) { return (u & 0x80000000u) | (v & 0x7fffffffu); };
+            int kk = 0;
+            for (; kk < N - M; ++kk) {
+                const uint32_t y = mix(s[kk], s[kk + 1]);
+                s[kk] = s[kk + M] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            }
+            for (; kk < N - 1; ++kk) {
+                const uint32_t y = mix(s[kk], s[kk + 1]);
+                s[kk] = s[kk + (M - N)] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            }
+            const uint32_t y = mix(s[N - 1], s[0]);
+            s[N - 1] = s[M - 1] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            pos = 0;
+        }
+        uint32_t y = s[pos++];
+        s[N] = pos;
+        y ^= y >> 11;
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= y >> 18;
+        return y;
+    }
+    uint32_t below(uint32_t n) {  // n >= 1
+        int k = 0;
+        for (uint32_t v = n; v; v >>= 1) ++k;
+        uint32_t r = next32() >> (32 - k);
+        while (r >= n) r = next32() >> (32 - k);
+        return r;
+    }
+};
+
+}  // namespace
+
+extern "C" int qp_place_sparse(int32_t which, int32_t T, int32_t Q, int32_t ldq, int32_t C, int32_t cap,
+                               const int32_t* member_ptr, const uint16_t* members, const int32_t* cmd_ptr,
+                               const int32_t* cmd_q0, const int32_t* cmd_q1, const int32_t* nb_ptr, const int32_t* nb,
+                               const double* D, uint32_t* mt_states, int32_t n_states, int32_t n_rep, uint8_t* A_out) {
+    if (which != QP_PLACE_RANDOM && which != QP_PLACE_BFS) return qp::fail(QP_EINVAL, "qp_place_sparse: unknown placer %d", which);
+    if (T < 0 || Q <= 0 || ldq < Q || C <= 0 || C > 255 || cap < 0 || n_rep < 0 || !member_ptr || !mt_states ||
+        (n_states != 1 && n_states != n_rep) || (n_rep > 0 && !A_out) || (member_ptr[T] > 0 && !members))
+        return qp::fail(QP_EINVAL, "qp_place_sparse: bad argument");
+    if (which == QP_PLACE_BFS && (!cmd_ptr || !nb_ptr || !D || (cmd_ptr[T] > 0 && (!cmd_q0 || !cmd_q1)) || (nb_ptr[C] > 0 && !nb)))
+        return qp::fail(QP_EINVAL, "qp_place_sparse: BFS needs the command lists, the neighbour lists and the distance matrix");
+    for (int32_t k = 0; k < member_ptr[T]; ++k)
+        if (members[k] >= Q) return qp::fail(QP_EINVAL, "qp_place_sparse: qubit index out of range");
+    if (which == QP_PLACE_BFS) {
+        for (int32_t k = 0; k < cmd_ptr[T]; ++k)
+            if (cmd_q0[k] >= Q || cmd_q1[k] >= Q) return qp::fail(QP_EINVAL, "qp_place_sparse: qubit index out of range");
+        for (int32_t k = 0; k < nb_ptr[C]; ++k)
+            if (nb[k] < 0 || nb[k] >= C) return qp::fail(QP_EINVAL, "qp_place_sparse: core index out of range");
+    }
+    std::vector<int32_t> room((size_t)C), open_nodes, queue, start;
+    std::vector<uint8_t> done((size_t)Q), seen((size_t)C);
+    for (int32_t rep = 0; rep < n_rep; ++rep) {
+        PyRandom rng(mt_states + (size_t)(n_states == 1 ? 0 : rep) * 625);
+        uint8_t* Ar = A_out + (size_t)rep * T * ldq;
+        for (int32_t t = 0; t < T; ++t) {
+            uint8_t* row = Ar + (size_t)t * ldq;
+            std::memset(row, QP_ABSENT, (size_t)Q);
+            std::memset(row + Q, 0, (size_t)(ldq - Q));
+            std::fill(room.begin(), room.end(), cap);
+            auto rebuild_open = [&]() {
+                open_nodes.clear();
+                for (int32_t n = 0; n < C; ++n)
+                    if (room[n] > 0) open_nodes.push_back(n);
+            };
+            const uint16_t* mem = members + member_ptr[t];
+            const int32_t n_mem = member_ptr[t + 1] - member_ptr[t];
+            if (which == QP_PLACE_RANDOM) {
+                rebuild_open();
+                for (int32_t k = 0; k < n_mem && !open_nodes.empty(); ++k) {
+                    const int32_t n = open_nodes[rng.below((uint32_t)open_nodes.size())];
+                    row[mem[k]] = (uint8_t)n;
+                    if (--room[n] == 0) rebuild_open();
+                }
+                continue;
+            }
+            for (int32_t k = 0; k < n_mem; ++k) done[mem[k]] = 0;
+            auto place = [&](int32_t q, int32_t n) {
+                row[q] = (uint8_t)n;
+                --room[n];
+                done[q] = 1;
+            };
+            for (int32_t c = cmd_ptr[t]; c < cmd_ptr[t + 1]; ++c) {
+                const int32_t a = cmd_q0[c], b = cmd_q1[c];
+                if (a < 0) continue;  // neither one nor two qubits: only a member of the slice
+                if (b >= 0) {
+                    if (done[a] || done[b]) continue;
+                    int32_t home = -1;
+                    for (int32_t n = 0; n < C && home < 0; ++n)
+                        if (room[n] >= 2) home = n;
+                    if (home >= 0) {
+                        place(a, home);
+                        place(b, home);
+                        continue;
+                    }
+                    // the closest pair of neighbouring cores with a free slot each; of equal distances the first
+                    // in (core, nearest-first neighbour) order, as a stable sort by distance leaves it
+                    int32_t b1 = -1, b2 = -1;
+                    double best = 0.0;
+                    for (int32_t n1 = 0; n1 < C; ++n1) {
+                        if (room[n1] < 1) continue;
+                        for (int32_t j = nb_ptr[n1]; j < nb_ptr[n1 + 1]; ++j) {
+                            const int32_t n2 = nb[j];
+                            if (room[n2] < 1) continue;
+                            const double d = D[(size_t)n1 * C + n2];
+                            if (b1 < 0 || d < best) {
+                                b1 = n1;
+                                b2 = n2;
+                                best = d;
+                            }
+                        }
+                    }
+                    if (b1 >= 0) {
+                        place(a, b1);
+                        place(b, b2);
+                    }
+                } else if (!done[a]) {
+                    rebuild_open();
+                    if (!open_nodes.empty()) place(a, open_nodes[rng.below((uint32_t)open_nodes.size())]);
+                }
+            }
+            // the rest, breadth-first from the emptiest cores
+            start.clear();
+            for (int32_t n = 0; n < C; ++n)
+                if (room[n] > 0) start.push_back(n);
+            std::stable_sort(start.begin(), start.end(), [&](int32_t x, int32_t y) { return room[x] > room[y]; });
+            queue.assign(start.begin(), start.end());
+            std::fill(seen.begin(), seen.end(), 0);
+            for (int32_t n : start) seen[n] = 1;
+            size_t head = 0;
+            for (int32_t k = 0; k < n_mem && head < queue.size(); ++k) {
+                const int32_t q = mem[k];
+                if (done[q]) continue;
+                const int32_t n = queue[head++];
+                place(q, n);
+                for (int32_t j = nb_ptr[n]; j < nb_ptr[n + 1]; ++j) {
+                    const int32_t m = nb[j];
+                    if (!seen[m] && room[m] > 0) {
+                        seen[m] = 1;
+                        queue.push_back(m);
+                    }
+                }
+            }
+        }
+    }
+    return QP_OK;
+}

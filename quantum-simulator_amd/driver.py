@@ -4,8 +4,9 @@ package's placers, with the work optionally sharded over the ranks of a torch.di
 Config format and required keys are the reference's (config_parser.py:20-84): ``key = value`` lines,
 ``#`` comments; keys mode, topology, num_cores_x, num_cores_y, ncm_qubits, ncp_qubits,
 edge_weight_range, circuit_folders, placers, repeats, out_csv, plot_file.  Optional additions
-(``batch_repeats = 0`` runs every repeat on its own as main.py does; by default the repeats of HQA, TRHQA
-and GTRHQA, which draw no random numbers, run as one device batch):
+(``batch_repeats = 0`` runs every repeat on its own as main.py does; by default the repeats of a placer run
+as one batch: HQA, TRHQA and GTRHQA, which draw no random numbers, on the device; RANDOM and BFS in a native
+loop that draws from ``random`` as the calls would, with one cost launch for all of them):
 ``seed`` (seeds Python's global ``random`` once before the architecture is built; the reference never
 seeds, so its runs are not reproducible) and ``device``.
 
@@ -177,11 +178,19 @@ def run_simulation(cfg, device=None, verbose=True):
                 continue
             if circuit is None:
                 circuit = circuit_from_qasm(path, maxwidth=1024)
-            # placers whose repeats do not depend on the random stream run them as one device batch
+            # the repeats of a placer run as one batch: HQA / TRHQA / GTRHQA placements advance together on the
+            # device; RANDOM / BFS placements run one after the other in the native loop (same draws from the
+            # random stream as one call per repeat) and are costed by one launch
             run_batch = getattr(placers[name], "run_repeats", None) if batched else None
             if run_batch is not None:
                 try:
-                    times, costs = run_batch(circuit, arch, len(mine))
+                    kw = {}
+                    if world > 1 and name in ("RANDOM", "BFS"):  # every repeat draws from its own seeded stream
+                        kw["states"] = []
+                        for rep in mine:
+                            random.seed(zlib.crc32(f"{seed}|{path}|{name}|{rep}".encode()))
+                            kw["states"].append(random.getstate())
+                    times, costs = run_batch(circuit, arch, len(mine), **kw)
                     for dt, cost in zip(times, costs):
                         record(fi, pi, dt, cost)
                     continue

@@ -17,7 +17,7 @@ from collections import deque
 import numpy as np
 
 from . import engine as E
-from ._lib import QP_ABSENT, QP_CM_GTRHQA, QP_CM_HQA, QP_CM_TRHQA, QP_V1, QP_V2, QP_V4, check, lib, ptr
+from ._lib import QP_ABSENT, QP_PLACE_BFS, QP_PLACE_RANDOM, QP_CM_GTRHQA, QP_CM_HQA, QP_CM_TRHQA, QP_V1, QP_V2, QP_V4, check, lib, ptr
 from .multicore import graph_tables
 from .timeslices import CircuitIR, circuit_ir
 
@@ -517,6 +517,8 @@ class gtrhqa_placer(_HqaFamily):
 # ------------------------------------------------------------------------------------------------
 
 class _SparsePlacer(BasePlacer):
+    _which = None  # QP_PLACE_RANDOM / QP_PLACE_BFS of the native form (place_batch)
+
     def per_timeslice_cost(self, circuit, partition, multicore_arch):
         """BFS_placer.py:202-239 == Random_placer.py:178-213."""
         ctx = self._context(circuit, multicore_arch)
@@ -524,11 +526,111 @@ class _SparsePlacer(BasePlacer):
             raise IndexError("list index out of range")
         return self._finish(ctx.cost(ctx.partition_array(partition, dense=False), QP_V2))
 
+    @staticmethod
+    def _slice_tables(ctx):
+        """What the placement loops read of the circuit, as integer tables (cached on the context): per slice
+        the active qubits in the order the reference walks its set of them (``list(set(...))`` of the command
+        objects' qubits: fixed by the qubits' hashes and the insertion order), and the commands in slice order."""
+        if getattr(ctx, "_sparse_tables", None) is None:
+            qidx = ctx.qindex
+            mptr, mem, cptr, c0, c1 = [0], [], [0], [], []
+            for layer in ctx.ir.command_slices():
+                members = set()
+                for cmd in layer:
+                    members.update(cmd.qubits)
+                mem.extend(qidx[q] for q in list(members))
+                mptr.append(len(mem))
+                for cmd in layer:
+                    qs = cmd.qubits
+                    if len(qs) == 2:
+                        c0.append(qidx[qs[0]])
+                        c1.append(qidx[qs[1]])
+                    elif len(qs) == 1:
+                        c0.append(qidx[qs[0]])
+                        c1.append(-1)
+                    else:
+                        c0.append(-1)
+                        c1.append(-1)
+                cptr.append(len(c0))
+            ctx._sparse_tables = (np.array(mptr, np.int32), np.array(mem, np.uint16), np.array(cptr, np.int32),
+                                  np.array(c0, np.int32), np.array(c1, np.int32))
+        return ctx._sparse_tables
+
+    @staticmethod
+    def _neighbour_tables(ctx, net):
+        """Neighbours of every core, nearest first (BFS_placer.py:7-18; Python's stable sort keeps adjacency
+        order among equal distances), as positions in ``list(net.nodes())``."""
+        if getattr(ctx, "_nb_tables", None) is None:
+            nodes = list(net.nodes())
+            pos = {n: i for i, n in enumerate(nodes)}
+            idx, D = ctx.arch.index, ctx.arch.D
+            nptr, nb = [0], []
+            for n in nodes:
+                order = list(net.neighbors(n))
+                order.sort(key=lambda m: D[idx[n], idx[m]])
+                nb.extend(pos[m] for m in order)
+                nptr.append(len(nb))
+            ctx._nb_tables = (np.array(nptr, np.int32), np.array(nb, np.int32))
+        return ctx._nb_tables
+
+    def place_batch(self, circuit, multicore_arch, B, states=None):
+        """``B`` placements in a row by the native form of ``place_per_timeslice`` (qp_place_sparse), drawing from
+        Python's global ``random`` stream exactly as B calls would and leaving it where they would; with
+        ``states`` (B results of ``random.getstate()``) repeat r draws from states[r] instead and the global
+        stream ends where the last of them ends.  Returns uint8 [B, T, ldq] rows as qp_slice_cost_v2 takes them
+        (QP_ABSENT = the qubit is not in the slice's dict)."""
+        ctx = self._context(circuit, multicore_arch)
+        net = multicore_arch.network
+        nodes = list(net.nodes())
+        if nodes != list(ctx.arch.nodes):
+            raise ValueError("core order of the distance tables differs from network.nodes()")
+        cap = int(multicore_arch.qpu_qubit_num)
+        mptr, mem, cptr, c0, c1 = self._slice_tables(ctx)
+        T, Q, ldq, C = ctx.ir.T, ctx.ir.Q, ctx.dc.ldq, ctx.arch.C
+        A = np.empty((B, T, ldq), np.uint8)
+        if states is None:
+            st = [random.getstate()]
+        else:
+            if len(states) != B:
+                raise ValueError("one generator state per placement")
+            st = list(states)
+        if any(s[0] != 3 for s in st):
+            raise ValueError("unknown random state version")
+        mt = np.array([s[1] for s in st], np.uint32)
+        if self._which == QP_PLACE_BFS:
+            nptr, nb = self._neighbour_tables(ctx, net)
+            D = np.ascontiguousarray(ctx.arch.D, np.float64)
+            args = (ptr(cptr), ptr(c0), ptr(c1), ptr(nptr), ptr(nb), ptr(D))
+        else:
+            args = (None,) * 6
+        check(lib().qp_place_sparse(self._which, T, Q, ldq, C, cap, ptr(mptr), ptr(mem), *args, ptr(mt), len(st), B, ptr(A)))
+        random.setstate((3, tuple(int(x) for x in mt[-1]), st[-1][2]))
+        for n in nodes:  # what the last slice of the last placement leaves on the architecture object
+            net.nodes[n]["qpu"].available_qubits = cap
+        if B and T and self._which == QP_PLACE_RANDOM:  # (the BFS loop only resets the counters at a slice's start)
+            used = np.bincount(A[-1, -1, :Q][A[-1, -1, :Q] != QP_ABSENT], minlength=C)
+            for i, n in enumerate(nodes):
+                net.nodes[n]["qpu"].available_qubits = cap - int(used[i])
+        return A
+
+    def run_repeats(self, circuit, multicore_arch, n, states=None):
+        """``n`` repeats of (place, cost) as main.py:88-92 runs them: the placements by the native loop, their
+        costs by one qp_slice_cost_v2 launch.  Returns (seconds per placement, costs)."""
+        import time
+        import torch
+        ctx = self._context(circuit, multicore_arch)
+        t0 = time.perf_counter()
+        A = self.place_batch(circuit, multicore_arch, n, states=states)
+        dt = (time.perf_counter() - t0) / max(n, 1)
+        costs = ctx.eng.cost_v2(ctx.dc, ctx.arch.table, torch.from_numpy(A).to(ctx.device), QP_V2).cpu().numpy()
+        return [dt] * n, [float(c) for c in costs]  # inf = the reference's cost loop raises for this repeat
+
 
 class random_placer(_SparsePlacer):
     def __init__(self, device=None):
         super().__init__(device)
         self.name = "RANDOM"
+        self._which = QP_PLACE_RANDOM
 
     def simulate_broken_links(self, circuit, multicore_arch, num_simulations=10, break_probability=0.1):
         """Random_placer.py:255-296 places with ``place_per_timeslice_weighted_aware`` (:61-142), an alternate
@@ -568,6 +670,7 @@ class bfs_placer(_SparsePlacer):
     def __init__(self, device=None):
         super().__init__(device)
         self.name = "BFS"
+        self._which = QP_PLACE_BFS
 
     def place_per_timeslice(self, circuit, multicore_arch):
         """BFS_placer.py:101-200.  Two-qubit gates go to the first core with two free slots, else to

@@ -140,6 +140,72 @@ def test_place_random_and_bfs(name):
     assert _rows_eq(rows, gc.part("RANDOM"))
 
 
+def _sparse_tables(gc):
+    """Integer tables qp_place_sparse reads: per slice the active qubits in the order ``list(set(...))`` of the
+    qubit objects yields them, the commands in slice order, every core's neighbours nearest first."""
+    keys = gc.qubit_objects()
+    back = {id(k): i for i, k in enumerate(keys)}
+    mptr, mem, cptr, c0, c1 = [0], [], [0], [], []
+    for sl in gc.slices:
+        members = set()
+        for g in sl:
+            members.update(keys[q] for q in gc.gate_q[g])
+        mem.extend(back[id(k)] for k in list(members))
+        mptr.append(len(mem))
+        for g in sl:
+            qs = gc.gate_q[g]
+            c0.append(qs[0] if len(qs) in (1, 2) else -1)
+            c1.append(qs[1] if len(qs) == 2 else -1)
+        cptr.append(len(c0))
+    adj = O.adjacency(gc.C, gc.edges)
+    nptr, nb = [0], []
+    for c in range(gc.C):
+        ns = [(v, gc.D[c][v]) for v, _ in adj[c]]
+        ns.sort(key=lambda x: x[1])
+        nb.extend(v for v, _ in ns)
+        nptr.append(len(nb))
+    i32 = lambda x: np.array(x, np.int32)  # noqa: E731
+    return i32(mptr), np.array(mem, np.uint16), i32(cptr), i32(c0), i32(c1), i32(nptr), i32(nb)
+
+
+@pytest.mark.parametrize("name", ALL_CASES)
+def test_native_random_and_bfs_placement(name):
+    """qp_place_sparse (host C++): three placements in a row from the fixture's seed.  The first equals the
+    reference's own placement (the fixture), all three equal three calls of the restatement on one stream, and
+    the generator is left in the state those calls leave it in; per-repeat states give each repeat its own."""
+    from quantum_simulator_amd._lib import QP_PLACE_BFS, QP_PLACE_RANDOM, check, lib, ptr
+    gc = load_case(name)
+    mptr, mem, cptr, c0, c1, nptr, nb = _sparse_tables(gc)
+    D = np.ascontiguousarray(gc.D, np.float64)
+    Dl = gc.D.tolist()
+    keys = gc.qubit_objects()
+    T, Q, C, cap = len(gc.slices), gc.Q, gc.C, gc.cap
+    ldq = (Q + 15) // 16 * 16
+    n = 3
+    for placer, which in (("RANDOM", QP_PLACE_RANDOM), ("BFS", QP_PLACE_BFS)):
+        rng = random.Random()
+        rng.seed(gc.meta["placers"][placer]["place_seed"])
+        st0 = rng.getstate()
+        want, states = [], []
+        for _ in range(n):
+            states.append(rng.getstate())
+            if placer == "BFS":
+                want.append(O.place_bfs(gc.slices, gc.gate_q, Q, C, cap, gc.edges, Dl, qubit_key=keys, rng=rng))
+            else:
+                want.append(O.place_random(gc.slices, gc.gate_q, Q, C, cap, qubit_key=keys, rng=rng))
+        for per_repeat in (False, True):
+            src = states if per_repeat else [st0]
+            mt = np.array([s[1] for s in src], np.uint32)
+            A = np.full((n, T, ldq), 7, np.uint8)
+            bfs = (ptr(cptr), ptr(c0), ptr(c1), ptr(nptr), ptr(nb), ptr(D)) if placer == "BFS" else (None,) * 6
+            check(lib().qp_place_sparse(which, T, Q, ldq, C, cap, ptr(mptr), ptr(mem), *bfs, ptr(mt), len(src), n, ptr(A)))
+            assert (A[0, :, :Q] == gc.part(placer)).all(), placer
+            for r in range(n):
+                assert _rows_eq(want[r], A[r, :, :Q]), (placer, r)
+            assert (A[:, :, Q:] == 0).all()
+            assert tuple(int(x) for x in mt[-1]) == rng.getstate()[1]
+
+
 def test_known_answer_386():
     """results.csv:2 of the reference: HQA == TRHQA == 386 x (the single edge weight) on the shipped
     example config; with unit weight the shipped code gives exactly 386."""
