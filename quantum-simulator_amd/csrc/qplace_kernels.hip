@@ -845,12 +845,14 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_grid_row(V3Args p) {
 // loads in flight: rows AHEAD steps ahead together with their slice bounds, the first 8 gate words of a
 // thread (two 16-byte loads from the padded gate list) AHEAD / 2 steps ahead.  Without the padded gate list
 // the gates come from the edge records, loaded where they are used (slower, same sums up to their order).
-// TABMODE: kTabLdsC (table staged in LDS at pitch C), kTabGlobal, kTabGrid.
+// TABMODE: kTabLdsC (table staged in LDS at pitch C), kTabGlobal, kTabGrid.  THREADS: 1024, or 512 for rows of up
+// to 8 KB when two workgroups then fit a CU (one alone has nothing to overlap the start and the end of an
+// item with); wherever the text above says 1024, read THREADS.
 constexpr int kWidePieces = 4;
 constexpr int kWideGateLoads = 2;  // 16-byte loads of gate words per thread and row that are prefetched
 
-template <int KIND, int TABMODE, int NP, int NBUF>
-__global__ __launch_bounds__(kV3Threads) void k_cost_v3_wide(V3Args p) {
+template <int KIND, int TABMODE, int NP, int NBUF, int THREADS>
+__global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void k_cost_v3_wide(V3Args p) {
     extern __shared__ __align__(16) uint8_t smem[];
     using E = typename Tab<KIND>::elem;
     using Acc = typename Tab<KIND>::acc;
@@ -869,8 +871,8 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_wide(V3Args p) {
     auto pair_at = [&](uint32_t from, uint32_t to) -> Acc { return (Acc)tab[min(from * C + to, last)]; };
     const int npieces = p.ldq / 16;
     int P = 128;  // rows here have more than 64 pieces, so a group is made of whole waves
-    while (P < npieces && P < kV3Threads) P *= 2;
-    const int groups = kV3Threads / P, tin = threadIdx.x % P;
+    while (P < npieces && P < THREADS) P *= 2;
+    const int groups = THREADS / P, tin = threadIdx.x % P;
     const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x / P);
     const int strip_bytes = P * 16 * NP;
     // the padded gate list, or (without one) any readable 16 bytes whose contents are ignored
@@ -885,7 +887,7 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_wide(V3Args p) {
     bool have[NP];
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
-        const int piece = tin + k * kV3Threads;
+        const int piece = tin + k * THREADS;
         have[k] = piece < npieces;
         off[k] = have[k] ? piece * 16 : 0;
 #pragma unroll
@@ -1047,7 +1049,7 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_wide(V3Args p) {
         __syncthreads();
         if (threadIdx.x == 0) {
             double tot = 0.0;
-            for (int w = 0; w < kV3Waves; ++w) tot += red[w];
+            for (int w = 0; w < (THREADS / kWave); ++w) tot += red[w];
             p.partial[it] = tot;
         }
         __syncthreads();  // the sums are read before the next item's rows overwrite them
@@ -1423,12 +1425,27 @@ extern "C" int qp_slice_cost_v3(const QpCircuit* circ, const QpDTable* dt, const
     }
     const int cus = qp::device_cus();
     p.rows_per_item = rows_per_item_for(T, p.G, B, cus);
+    // rows longer than 1 KB: workgroup size, LDS contents and rows per item of k_cost_v3_wide
+    int wide_threads = kV3Threads;
+    size_t wide_tab = 0, wide_strips = 0;
+    bool wide_two = false;
     if (!narrow) {
-        // the wide kernel splits an item's rows over 1024 / P thread groups (P as the kernel forms it): runs
-        // of at least 32 rows per group, so a run's start-up (one extra row, the first loads waited for) is small
-        int P = 64;
-        while (P < ldq / 16 && P < kV3Threads) P *= 2;
-        p.rows_per_item = std::min<int>(T, std::max(p.rows_per_item, 32 * (kV3Threads / P)));
+        if (ldq / 16 > kWidePieces * kV3Threads) return qp::fail(QP_EINVAL, "qp_slice_cost_v3: rows longer than 65536 bytes");
+        const bool gridpath = dt->kind == QP_DT_U16 && dt->grid.valid;
+        // the table (if it fits beside one set of strips) and one or two strips of a row per group
+        wide_strips = (size_t)kV3Threads * 16 * (ldq / 16 <= kV3Threads ? 1 : kWidePieces);
+        if (!gridpath && tab_padded + wide_strips <= (size_t)kLdsBytes) wide_tab = tab_padded;
+        // half-size workgroups when two of them (table and two strips each) fit a CU
+        if (ldq / 16 <= kV3Threads / 2 && 2 * (wide_tab + wide_strips) <= (size_t)kLdsBytes) {
+            wide_threads = kV3Threads / 2;
+            wide_strips /= 2;
+        }
+        wide_two = wide_tab + 2 * wide_strips <= (size_t)kLdsBytes;
+        // an item's rows are split over threads / P thread groups (P as the kernel forms it): runs of at least
+        // 32 rows per group, so a run's start-up (one extra row, the first loads waited for) is small
+        int P = 128;
+        while (P < ldq / 16 && P < wide_threads) P *= 2;
+        p.rows_per_item = std::min<int>(T, std::max(p.rows_per_item, 32 * (wide_threads / P)));
     }
     const int32_t nchunks = (T + p.rows_per_item - 1) / p.rows_per_item;
     p.nitems = (int64_t)nchunks * B;
@@ -1535,17 +1552,15 @@ extern "C" int qp_slice_cost_v3(const QpCircuit* circ, const QpDTable* dt, const
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         kern<<<grid, kV3Threads, lds, stream>>>(p);
     } else {
-        if (ldq / 16 > kWidePieces * kV3Threads) return qp::fail(QP_EINVAL, "qp_slice_cost_v3: rows longer than 65536 bytes");
         const bool gridpath = dt->kind == QP_DT_U16 && dt->grid.valid;
-        // LDS: the table (if it fits beside one set of strips) and one or two strips of a row per group
         const bool one = ldq / 16 <= kV3Threads;  // one piece per thread
-        const size_t strip_set = (size_t)kV3Threads * 16 * (one ? 1 : kWidePieces);
-        const bool tab_lds = !gridpath && tab_padded + strip_set <= (size_t)kLdsBytes;
-        const bool two = (tab_lds ? tab_padded : 0) + 2 * strip_set <= (size_t)kLdsBytes;
+        const bool half = wide_threads < kV3Threads, two = wide_two, tab_lds = wide_tab > 0;
+        const int threads = wide_threads;
         void (*kern)(V3Args) = nullptr;
 #define QP_WIDE(KIND, MODE) \
-    (one ? (two ? k_cost_v3_wide<KIND, MODE, 1, 2> : k_cost_v3_wide<KIND, MODE, 1, 1>) \
-         : (two ? k_cost_v3_wide<KIND, MODE, kWidePieces, 2> : k_cost_v3_wide<KIND, MODE, kWidePieces, 1>))
+    (half ? k_cost_v3_wide<KIND, MODE, 1, 2, kV3Threads / 2> \
+     : one ? (two ? k_cost_v3_wide<KIND, MODE, 1, 2, kV3Threads> : k_cost_v3_wide<KIND, MODE, 1, 1, kV3Threads>) \
+           : (two ? k_cost_v3_wide<KIND, MODE, kWidePieces, 2, kV3Threads> : k_cost_v3_wide<KIND, MODE, kWidePieces, 1, kV3Threads>))
         if (gridpath) {
             if (int rc = fill_grid_args(p, dt)) return rc;
             kern = QP_WIDE(QP_DT_U16, kTabGrid);
@@ -1555,12 +1570,12 @@ extern "C" int qp_slice_cost_v3(const QpCircuit* circ, const QpDTable* dt, const
             kern = tab_lds ? QP_WIDE(QP_DT_U16, kTabLdsC) : QP_WIDE(QP_DT_U16, kTabGlobal);
         }
 #undef QP_WIDE
-        const size_t lds = (tab_lds ? tab_padded : 0) + (two ? 2 : 1) * strip_set;
+        const size_t lds = wide_tab + (two ? 2 : 1) * wide_strips;
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int per_cu = 1;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), kV3Threads, lds));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), threads, lds));
         const unsigned grid = (unsigned)std::min<int64_t>((int64_t)cus * std::max(per_cu, 1), p.nitems);
-        kern<<<grid, kV3Threads, lds, stream>>>(p);
+        kern<<<grid, threads, lds, stream>>>(p);
     }
     HIP_TRY(hipGetLastError());
     k_sum_chunks<<<(unsigned)((B + 255) / 256), 256, 0, stream>>>(p.partial, B, nchunks, out);
