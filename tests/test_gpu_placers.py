@@ -411,3 +411,57 @@ def test_simulate_broken_links_matches_reference_fixture(key):
         else:
             w = float.fromhex(want["cost"])
             assert abs(cost - w) <= 1e-12 * abs(w), (cost, w)
+
+
+_TWO_RANK_WORKER = """
+import json, os, sys
+sys.path.insert(0, {root!r})
+import torch
+import torch.distributed as dist
+from quantum_simulator_amd import driver
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=2)
+cfg = driver.parse_config_file({cfg!r})
+cfg["out_csv"] = {out!r} + os.environ["RANK"]
+out = []
+for batched in (1, 0):
+    res = driver.run_simulation(dict(cfg, batch_repeats=batched), verbose=False)
+    out.append([[r[k] for k in sorted(r) if k.endswith("cost_mean") or k.endswith("cost_min")] for r in res])
+print("RESULT " + json.dumps(out))
+dist.destroy_process_group()
+"""
+
+
+def test_driver_two_ranks_share_the_gpu(tmp_path):
+    """The driver on two gloo ranks that share cuda:0, real placers: the repeats of RANDOM / BFS (seeded per
+    unit when there is more than one rank) and of HQA give the same table whether a rank runs its repeats as
+    one batch or one at a time, and both ranks end with the same table."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from quantum_simulator_amd import circuit_to_qasm_str, layered_circuit
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    folder = tmp_path / "circ"
+    folder.mkdir()
+    for k, (q, t) in enumerate([(12, 9), (20, 6)]):
+        (folder / f"c{k}.qasm").write_text(circuit_to_qasm_str(layered_circuit(q, t, 0.5, seed=k)))
+    cfg = tmp_path / "cfg.txt"
+    cfg.write_text(f"mode = simulate\ntopology = mesh\nnum_cores_x = 3\nnum_cores_y = 2\nncm_qubits = 4\nncp_qubits = 4\n"
+                   f"edge_weight_range = 1.0,3.0\ncircuit_folders = {folder}\nplacers = RANDOM, BFS, HQA\nrepeats = 5\n"
+                   f"out_csv = {tmp_path / 'o.csv'}\nplot_file = \nseed = 11\n")
+    script = tmp_path / "w.py"
+    script.write_text(_TWO_RANK_WORKER.format(root=root, cfg=str(cfg), out=str(tmp_path / "o.csv")))
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        out, _ = p.communicate(timeout=300)
+        assert p.returncode == 0, out
+        outs.append(json.loads([l for l in out.splitlines() if l.startswith("RESULT ")][0][7:]))
+    assert outs[0] == outs[1]
+    batched, single = outs[0]
+    assert batched == single and len(batched) == 2
+    assert all(np.isfinite(x) for row in batched for x in row)
