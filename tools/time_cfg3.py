@@ -35,7 +35,7 @@ def main():
     for case in ("qft29_torus8x8_u", "qft63_torus8x8_u"):
         with open(os.path.join(folder, case.split("_")[0] + ".qasm"), "w") as f:
             f.write(qasm_of(load_case(case)))
-    for placer in ("GTRHQA", "HQA", "TRHQA", "BFS", "RANDOM"):
+    for placer in ("GTRHQA", "GTRHQA", "HQA", "TRHQA", "BFS", "RANDOM"):  # the first pass also loads the library and starts HIP
         cfg_path = os.path.join(out, f"config_{placer}.txt")
         with open(cfg_path, "w") as f:
             f.write(f"mode = simulate\ntopology = torus\nnum_cores_x = 8\nnum_cores_y = 8\nncm_qubits = 4\nncp_qubits = 2\n"
