@@ -13,6 +13,8 @@ import os
 import random
 import sys
 
+import numpy as np
+
 sys.dont_write_bytecode = True
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
@@ -20,7 +22,11 @@ import gen_golden as G  # noqa: E402
 
 RUNS = [("qft18_mesh4x4_u", "HQA", 4242, 6, 0.15), ("shor5_mesh2x2_i", "HQA", 99, 8, 0.3),
         ("qft29_torus8x8_u", "HQA", 5, 3, 0.1), ("qft18_mesh4x4_u", "TRHQA", 17, 5, 0.15),
-        ("bigadder_mesh4x4_u", "BFS", 23, 5, 0.2)]  # Random_placer's variant calls an alternate placement: not covered
+        ("bigadder_mesh4x4_u", "BFS", 23, 5, 0.2),
+        # Random_placer's variant places with place_per_timeslice_weighted_aware, which also draws from numpy's global
+        # generator (seeded with the same number); capacity 4 on 16 cores leaves qft_n63 no core with two free slots
+        ("qft63_mesh4x4_cap4_u", "RANDOM", 31, 4, 0.15), ("qft18_mesh4x4_u", "RANDOM", 7, 5, 0.2),
+        ("shor5_mesh2x2_i", "RANDOM", 3, 6, 0.3)]
 CLS = {"HQA": "hqa_placer", "TRHQA": "trhqa_placer", "BFS": "bfs_placer", "RANDOM": "random_placer"}
 
 
@@ -36,12 +42,51 @@ def main():
         eidx = {e: i for i, e in enumerate(edges)}
         placer = getattr(R[pname], CLS[pname])()
         random.seed(seed)
+        np.random.seed(seed)
         with contextlib.redirect_stdout(io.StringIO()):
             res = placer.simulate_broken_links(circ, arch, num_simulations=nsim, break_probability=prob)
         out[f"{name}/{pname}"] = dict(seed=seed, num_simulations=nsim, break_probability=prob,
                          sims=[dict(broken=sorted(eidx[e] for e in b),
                                     cost="inf" if c == float("inf") else float(c).hex()) for b, c in res])
         print(name, pname, [(len(s["broken"]), s["cost"]) for s in out[f"{name}/{pname}"]["sims"]], flush=True)
+    # a circuit of this package's own generator whose slices hold more two-qubit gates than there are cores with
+    # two free slots (12 qubits, 6 cx per slice, mesh 2x2 with 3 slots per core): Random_placer's weight-biased
+    # choice of a pair of cores (np.random.choice) is drawn; the QASM text travels inside the fixture
+    import tempfile
+    sys.path.insert(0, os.path.dirname(HERE))
+    from quantum_simulator_amd import circuit_to_qasm_str, layered_circuit
+    for key, (q, t, cseed), (topo, nxx, nyy, cap, wr, aseed), seed, nsim, prob in [
+            ("layered12x8_mesh2x2_cap3/RANDOM", (12, 8, 5), ("mesh", 2, 2, 3, (1.0, 3.0), 41), 77, 5, 0.2),
+            ("layered20x6_torus3x3_cap3/RANDOM", (20, 6, 9), ("torus", 3, 3, 3, (1.0, 3.0), 42), 78, 4, 0.1)]:
+        text = circuit_to_qasm_str(layered_circuit(q, t, 1.0, seed=cseed))
+        with tempfile.TemporaryDirectory() as tmp:
+            path = os.path.join(tmp, "c.qasm")
+            with open(path, "w") as f:
+                f.write(text)
+            circ = R["qasm"].circuit_from_qasm(path, maxwidth=1024)
+        arch = G._build_arch(R, topo, nxx, nyy, cap, wr, aseed)
+        eidx = {e: i for i, e in enumerate(arch.network.edges)}
+        placer = R["RANDOM"].random_placer()
+        random.seed(seed)
+        np.random.seed(seed)
+        drawn = [0]
+        plain = np.random.choice
+
+        def counted(*a, **k):
+            drawn[0] += 1
+            return plain(*a, **k)
+        np.random.choice = counted
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                res = placer.simulate_broken_links(circ, arch, num_simulations=nsim, break_probability=prob)
+        finally:
+            np.random.choice = plain
+        out[key] = dict(seed=seed, num_simulations=nsim, break_probability=prob, qasm=text,
+                        arch=dict(topology=topo, nx=nxx, ny=nyy, cap=cap, weight_range=list(wr), arch_seed=aseed),
+                        numpy_choices=drawn[0],
+                        sims=[dict(broken=sorted(eidx[e] for e in b),
+                                   cost="inf" if c == float("inf") else float(c).hex()) for b, c in res])
+        print(key, "np.random.choice calls:", drawn[0], [(len(s["broken"]), s["cost"]) for s in out[key]["sims"]], flush=True)
     with open(os.path.join(G.OUT, "broken_links.json"), "w") as f:
         json.dump(out, f, separators=(",", ":"))
 

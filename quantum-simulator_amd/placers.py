@@ -633,9 +633,74 @@ class random_placer(_SparsePlacer):
         self._which = QP_PLACE_RANDOM
 
     def simulate_broken_links(self, circuit, multicore_arch, num_simulations=10, break_probability=0.1):
-        """Random_placer.py:255-296 places with ``place_per_timeslice_weighted_aware`` (:61-142), an alternate
-        placement that no configuration reaches and that this package does not provide."""
-        raise NotImplementedError("random_placer.simulate_broken_links needs place_per_timeslice_weighted_aware")
+        """Random_placer.py:255-296: as the other placers' (one ``random.random()`` per link and simulation), but
+        every damaged network is placed with ``place_per_timeslice_weighted_aware``."""
+        plain = self.place_per_timeslice
+        self.place_per_timeslice = self.place_per_timeslice_weighted_aware
+        try:
+            return super().simulate_broken_links(circuit, multicore_arch, num_simulations, break_probability)
+        finally:
+            self.place_per_timeslice = plain
+
+    def place_per_timeslice_weighted_aware(self, circuit, multicore_arch, bias_factor=0.3):
+        """Random_placer.py:61-142.  Per slice: a two-qubit gate whose qubits are both unplaced goes to a random
+        core with two free slots; when there is none, to a pair of cores with a free slot each, drawn (with
+        probability ``bias_factor``, one ``random.random()``) by numpy's global ``np.random.choice`` with
+        probabilities proportional to 1 / (distance + 0.1) (0.1 for an infinite distance), else by
+        ``random.choice`` over the pairs; every qubit still unplaced then draws ``random.choice`` over the cores
+        with room, in gate order."""
+        net = multicore_arch.network
+        cap = multicore_arch.qpu_qubit_num
+        nodes = list(net.nodes())
+        result = []
+        for layer in self.break_into_timeslices(circuit):
+            room = {n: cap for n in nodes}
+            row = {}
+            placed = set()
+            for cmd in layer:
+                if len(cmd.qubits) != 2:
+                    continue
+                a, b = cmd.qubits
+                if a in placed or b in placed:
+                    continue
+                homes = [n for n in nodes if room[n] >= 2]
+                if homes:
+                    home = random.choice(homes)
+                    row[a] = row[b] = home
+                    room[home] -= 2
+                    placed.update((a, b))
+                    continue
+                open_nodes = [n for n in nodes if room[n] > 0]
+                if len(open_nodes) < 2:
+                    continue
+                pairs, probs = [], []
+                for i, n1 in enumerate(open_nodes):
+                    for n2 in open_nodes[i + 1:]:
+                        w = self.get_weighted_distance(multicore_arch, n1, n2)
+                        pairs.append((n1, n2))
+                        probs.append(1.0 / (w + 0.1) if w != float("inf") else 0.1)
+                if random.random() < bias_factor:
+                    total = sum(probs)
+                    n1, n2 = pairs[np.random.choice(len(pairs), p=[x / total for x in probs])]
+                else:
+                    n1, n2 = random.choice(pairs)
+                row[a], row[b] = n1, n2
+                room[n1] -= 1
+                room[n2] -= 1
+                placed.update((a, b))
+            for cmd in layer:
+                for q in cmd.qubits:
+                    if q not in placed:
+                        open_nodes = [n for n in nodes if room[n] > 0]
+                        if open_nodes:
+                            n = random.choice(open_nodes)
+                            row[q] = n
+                            room[n] -= 1
+                            placed.add(q)
+            for n in nodes:
+                net.nodes[n]["qpu"].available_qubits = room[n]
+            result.append(row)
+        return result
 
     def place_per_timeslice(self, circuit, multicore_arch):
         """Random_placer.py:25-59: per slice, every active qubit (in ``list(set(...))`` order) draws

@@ -383,8 +383,10 @@ def test_gtrhqa_full_size_invariants():
 
 
 @pytest.mark.parametrize("key", ["qft18_mesh4x4_u/HQA", "shor5_mesh2x2_i/HQA", "qft29_torus8x8_u/HQA",
-                                 "qft18_mesh4x4_u/TRHQA", "bigadder_mesh4x4_u/BFS"])
-def test_simulate_broken_links_matches_reference_fixture(key):
+                                 "qft18_mesh4x4_u/TRHQA", "bigadder_mesh4x4_u/BFS", "qft63_mesh4x4_cap4_u/RANDOM",
+                                 "qft18_mesh4x4_u/RANDOM", "shor5_mesh2x2_i/RANDOM", "layered12x8_mesh2x2_cap3/RANDOM",
+                                 "layered20x6_torus3x3_cap3/RANDOM"])
+def test_simulate_broken_links_matches_reference_fixture(key, tmp_path):
     """simulate_broken_links under the same seed as the unmodified reference
     (tests/golden/broken_links.json): same links broken in every simulation, same cost (infinite where
     the damaged network forces a move across a broken link)."""
@@ -395,14 +397,36 @@ def test_simulate_broken_links_matches_reference_fixture(key):
     from quantum_simulator_amd.placers import PLACERS
     name, pname = key.split("/")
     gold = json.load(open(os.path.join(ROOT, "tests", "golden", "broken_links.json")))[key]
-    gc = load_case(name)
-    circ, arch = case_circuit(gc), case_arch(gc)
+    if "qasm" in gold:  # a generated circuit whose text travels in the fixture, with its architecture's parameters
+        from quantum_simulator_amd.circuit import circuit_from_qasm
+        from quantum_simulator_amd.multicore import multicore
+        (tmp_path / "c.qasm").write_text(gold["qasm"])
+        circ = circuit_from_qasm(str(tmp_path / "c.qasm"), maxwidth=1024)
+        m = gold["arch"]
+        random.seed(m["arch_seed"])
+        arch = multicore(m["nx"], m["ny"], ncm_qubits=4, ncp_qubits=m["cap"], edge_weight_range=tuple(m["weight_range"]),
+                         network_type=m["topology"])
+    else:
+        gc = load_case(name)
+        circ, arch = case_circuit(gc), case_arch(gc)
     before = arch.network
     eidx = {e: i for i, e in enumerate(arch.network.edges)}
     random.seed(gold["seed"])
-    got = PLACERS[pname]().simulate_broken_links(circ, arch, num_simulations=gold["num_simulations"],
-                                                 break_probability=gold["break_probability"])
+    np.random.seed(gold["seed"])  # (random_placer's weight-biased choice of a core pair draws from numpy's generator)
+    drawn = [0]
+    plain = np.random.choice
+
+    def counted(*a, **k):
+        drawn[0] += 1
+        return plain(*a, **k)
+    np.random.choice = counted
+    try:
+        got = PLACERS[pname]().simulate_broken_links(circ, arch, num_simulations=gold["num_simulations"],
+                                                     break_probability=gold["break_probability"])
+    finally:
+        np.random.choice = plain
     assert arch.network is before
+    assert drawn[0] == gold.get("numpy_choices", 0)
     assert len(got) == len(gold["sims"])
     for (broken, cost), want in zip(got, gold["sims"]):
         assert sorted(eidx[e] for e in broken) == want["broken"]
