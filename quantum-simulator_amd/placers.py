@@ -157,6 +157,30 @@ class BasePlacer:
             tabs = self._dist_tabs
         return self._as_distance(tabs.D[tabs.index[node1], tabs.index[node2]])
 
+    def _host_tables(self, multicore_arch):
+        """Node order and distance matrix of an architecture; needs no GPU."""
+        fp = _ArchTables.fingerprint(multicore_arch.network)
+        if self._ctx is not None and self._ctx_key[2] == fp:
+            return self._ctx.arch
+        if getattr(self, "_dist_key", None) != fp:
+            self._dist_tabs = _ArchTables(multicore_arch.network)
+            self._dist_key = fp
+        return self._dist_tabs
+
+    def _get_average_weighted_distance(self, multicore_arch):
+        """HQA_placer.py:242-257 (== TRHQA / GTRHQA): mean finite distance over unordered pairs of cores, summed in
+        (i, j > i) order of ``network.nodes``; 1.0 without a finite pair."""
+        tabs = self._host_tables(multicore_arch)
+        nodes = list(multicore_arch.network.nodes)
+        total, pairs = 0, 0
+        for i in range(len(nodes)):
+            for j in range(i + 1, len(nodes)):
+                w = self._as_distance(tabs.D[tabs.index[nodes[i]], tabs.index[nodes[j]]])
+                if w != float("inf"):
+                    total += w
+                    pairs += 1
+        return total / pairs if pairs > 0 else 1.0
+
     @staticmethod
     def _as_distance(x):
         x = float(x)
@@ -210,6 +234,18 @@ class BasePlacer:
 # ------------------------------------------------------------------------------------------------
 # HQA / TRHQA / GTRHQA
 # ------------------------------------------------------------------------------------------------
+
+def random_initial_assignment(all_qubits, core_nodes, qubits_per_core, seed=None):
+    """HQA_placer.py:8-18 (== TRHQA_placer.py, GTRHQA_placer.py): every core ``qubits_per_core`` times, shuffled by
+    the global ``random`` stream (seeded first if ``seed`` is given), dealt to the qubits in order."""
+    if seed is not None:
+        random.seed(seed)
+    slots = []
+    for c in core_nodes:
+        slots.extend([c] * qubits_per_core)
+    random.shuffle(slots)
+    return dict(zip(all_qubits, slots))
+
 
 class _HqaFamily(BasePlacer):
     _kind = QP_CM_HQA
@@ -642,6 +678,43 @@ class random_placer(_SparsePlacer):
         finally:
             self.place_per_timeslice = plain
 
+    def place(self, circuit, multicore_arch):
+        """Random_placer.py:9-23: one core per qubit, a ``random.sample`` of the cores; None (after the
+        reference's message) when there are more qubits than cores."""
+        nodes = list(multicore_arch.network.nodes())
+        qubits = circuit.qubits
+        if len(qubits) > len(nodes):
+            print("Error: Not enough unique QPU nodes to place all qubits.")
+            return None
+        return dict(zip(qubits, random.sample(nodes, len(qubits))))
+
+    def get_placement_statistics(self, circuit, partition, multicore_arch):
+        """Random_placer.py:214-253: counts of two-qubit gates and of those split over two cores, with the
+        weighted and hop distances of the split ones (slice order) and their means."""
+        tabs = self._host_tables(multicore_arch)
+        H = E.hops(tabs.C, tabs.eu, tabs.ev)
+        ir = circuit_ir(circuit)
+        layers = ir.command_slices()
+        stats = {"total_timeslices": len(layers), "total_partitions": len(partition), "weighted_distances": [],
+                 "unweighted_distances": [], "two_qubit_gates": 0, "cross_qpu_gates": 0}
+        for i, layer in enumerate(layers):
+            for g, cmd in zip(ir.slices[i], layer):
+                if len(cmd.qubits) == 2 and not ir.gate_mr[g]:
+                    stats["two_qubit_gates"] += 1
+                    a, b = cmd.qubits
+                    na, nb = partition[i][a], partition[i][b]
+                    if na != nb:
+                        stats["cross_qpu_gates"] += 1
+                        stats["weighted_distances"].append(self._as_distance(tabs.D[tabs.index[na], tabs.index[nb]]))
+                        stats["unweighted_distances"].append(int(H[tabs.index[na], tabs.index[nb]]))
+        if stats["weighted_distances"]:
+            stats["avg_weighted_distance"] = np.mean(stats["weighted_distances"])
+            stats["avg_unweighted_distance"] = np.mean(stats["unweighted_distances"])
+        else:
+            stats["avg_weighted_distance"] = 0
+            stats["avg_unweighted_distance"] = 0
+        return stats
+
     def place_per_timeslice_weighted_aware(self, circuit, multicore_arch, bias_factor=0.3):
         """Random_placer.py:61-142.  Per slice: a two-qubit gate whose qubits are both unplaced goes to a random
         core with two free slots; when there is none, to a pair of cores with a free slot each, drawn (with
@@ -736,6 +809,74 @@ class bfs_placer(_SparsePlacer):
         super().__init__(device)
         self.name = "BFS"
         self._which = QP_PLACE_BFS
+
+    def _get_weighted_neighbors_sorted(self, multicore_arch, node):
+        """BFS_placer.py:7-18: the neighbours of a core, nearest first (stable among equal distances)."""
+        tabs = self._host_tables(multicore_arch)
+        nb = list(multicore_arch.network.neighbors(node))
+        nb.sort(key=lambda m: self._as_distance(tabs.D[tabs.index[node], tabs.index[m]]))
+        return nb
+
+    def place(self, circuit, multicore_arch):
+        """BFS_placer.py:20-99: one placement for the whole circuit, on the free slots the architecture's core
+        objects hold when it is called (they are not reset).  Two-qubit gates in circuit order: both qubits to the
+        first core with two free slots, else (after ``random.shuffle`` of the core list, which stays shuffled) to
+        the first core with a free slot and its nearest neighbour with one; the other qubits breadth-first from
+        the emptiest cores; what is still left draws ``random.choice``."""
+        net = multicore_arch.network
+        nodes = list(net.nodes())
+        free = {n: net.nodes[n]["qpu"].available_qubits for n in nodes}
+        row, placed = {}, set()
+        for cmd in circuit:
+            if len(cmd.qubits) != 2:
+                continue
+            a, b = cmd.qubits[0], cmd.qubits[1]
+            if a in placed or b in placed:
+                continue
+            for n in nodes:
+                if free[n] >= 2:
+                    row[a] = row[b] = n
+                    free[n] -= 2
+                    placed.update((a, b))
+                    break
+            if a not in placed:
+                random.shuffle(nodes)
+                found = False
+                for n1 in nodes:
+                    if free[n1] >= 1:
+                        for n2 in self._get_weighted_neighbors_sorted(multicore_arch, n1):
+                            if free[n2] >= 1:
+                                row[a], row[b] = n1, n2
+                                free[n1] -= 1
+                                free[n2] -= 1
+                                placed.update((a, b))
+                                found = True
+                                break
+                        if found:
+                            break
+        waiting = [q for q in list(circuit.qubits) if q not in placed]
+        if waiting:
+            start = [(n, free[n]) for n in nodes if free[n] > 0]
+            start.sort(key=lambda x: x[1], reverse=True)
+            queue = deque(n for n, _ in start)
+            seen = set(queue)
+            while queue and waiting:
+                n = queue.popleft()
+                row[waiting.pop(0)] = n
+                free[n] -= 1
+                for m in self._get_weighted_neighbors_sorted(multicore_arch, n):
+                    if m not in seen and free[m] > 0:
+                        seen.add(m)
+                        queue.append(m)
+            for q in waiting:
+                open_nodes = [n for n in nodes if free[n] > 0]
+                if open_nodes:
+                    n = random.choice(open_nodes)
+                    row[q] = n
+                    free[n] -= 1
+        for n in free:
+            net.nodes[n]["qpu"].available_qubits = free[n]
+        return row
 
     def place_per_timeslice(self, circuit, multicore_arch):
         """BFS_placer.py:101-200.  Two-qubit gates go to the first core with two free slots, else to
