@@ -18,7 +18,8 @@ few doubles) is done once after it and reported as ``reduce_ms``.
 Rank 0 prints one JSON line.  ``roofline`` prices the dominant kernel of the headline variant against
 HBM: algorithmic bytes per launch / mean launch time from HIP events on the launch stream.
 ``other_variants`` repeats the measurement with table look-ups forced and with non-integer weights
-(fp64 table); ``gtrhqa_place``, ``cost_matrix`` and ``qubo`` time the other device paths.
+(fp64 table); ``gtrhqa_place``, ``cost_matrix`` and ``qubo`` time the other device paths, ``shipped_circuits``
+whole placement + cost batches of every placer on two of the reference's own circuits.
 ``cpu_baseline`` times the CPU oracle (a C port of the reference's per_timeslice_cost loop) on a bounded
 sample of the same partitions on every host core, each result checked against the GPU's.
 """
@@ -142,6 +143,28 @@ def bench_cost_matrix(torch, dev, dc, ir, D, B, steps):
             "entries_per_s": entries / (ms * 1e-3),
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                          "note": "8 bytes written per entry; inputs are re-read from cache"}}
+
+
+def bench_shipped(dev):
+    """The reference's shipped circuits (gate tables from tests/golden; the QASM files themselves do not travel):
+    batches of whole placements + their costs, as the driver runs a config's repeats.  cfg2 = qft_n18 on the 4x4
+    mesh, cfg3 = qft_n63 on the 8x8 torus (one GPU's share of 64 repeats is 8; 64 are run)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import case_arch, case_circuit, load_case
+    from quantum_simulator_amd.placers import PLACERS
+    rows = []
+    for cfg, name, B in (("cfg2", "qft18_mesh4x4_u", 256), ("cfg3", "qft63_torus8x8_u", 64)):
+        gc = load_case(name)
+        circ, arch = case_circuit(gc), case_arch(gc)
+        for pname in ("HQA", "TRHQA", "GTRHQA", "BFS", "RANDOM"):
+            placer = PLACERS[pname](dev)
+            placer.run_repeats(circ, arch, 2)
+            t0 = time.perf_counter()
+            _, costs = placer.run_repeats(circ, arch, B)
+            wall = time.perf_counter() - t0
+            rows.append({"config": cfg, "case": name, "placer": pname, "repeats": B, "slices": gc.T,
+                         "seconds": wall, "slice_steps_per_s": B * gc.T / wall, "mean_cost": float(sum(costs) / len(costs))})
+    return rows
 
 
 def main():
@@ -336,6 +359,12 @@ def main():
             fl = torch.tensor([qubo["spin_flip_attempts_per_s"]], dtype=torch.float64, device=dev)
             dist.all_reduce(fl, op=dist.ReduceOp.SUM)
             qubo["spin_flip_attempts_per_s"] = float(fl.item())
+    shipped = None
+    if world == 1 and not args.no_qubo:
+        try:
+            shipped = bench_shipped(dev)
+        except Exception as exc:  # noqa: BLE001 - a side table must not cost the headline line
+            shipped = {"error": f"{type(exc).__name__}: {exc}"}
     if rank == 0:
         D, kind, gpu_costs = primary.pop("_D"), primary.pop("_kind"), primary.pop("_costs")
         res = {
@@ -351,6 +380,7 @@ def main():
                        "table": primary["table"]},
             "roofline": primary["roofline"], "mean_cost": primary["mean_cost"], "min_cost": primary["min_cost"],
             "reduce_ms": primary["reduce_ms"], "gtrhqa_place": place, "cost_matrix": cm, "qubo": qubo,
+            "shipped_circuits": shipped,
         }
         # HBM bytes per launch as measured with rocprofv3 PMC counters in a separate run of this workload
         # (profiles/r01_traffic.json; FETCH_SIZE doubled as gfx950 requires for 16-byte-per-lane streams)
