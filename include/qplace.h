@@ -233,6 +233,20 @@ size_t qp_slice_cost_workspace(int32_t T, int64_t B);
 int qp_slice_cost_v3(const QpCircuit* circ, const QpDTable* dt, const uint8_t* A, int64_t B, int32_t Tp,
                      int32_t ldq, double* out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* qp_slice_cost_v3 for callers that cannot allocate device memory or hand over a workspace: code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc.  No counterpart in the reference.
+ * Same arguments, same kernels and bit-for-bit the same results as qp_slice_cost_v3; the partial sums (and
+ * the symmetrised triangle of a large fp64 table) live in a QP_STATIC_SCRATCH_BYTES array inside the
+ * library's code object, of which every GPU holds its own copy until the process ends.  The call allocates
+ * and frees nothing.  A batch that needs more scratch (about one double per partition and chunk of 16..256
+ * slices, plus 256 KB for an fp64 table of more than 134 cores) is refused with QP_ENOSPC: split it, or use
+ * qp_slice_cost_v3.  Calls on one GPU share that GPU's array: two of them in flight at once on different
+ * streams race (calls on one stream are ordered and safe; nothing has to be cleared between calls). */
+#define QP_STATIC_SCRATCH_BYTES (4u << 20)
+size_t qp_static_scratch_bytes(void);
+int qp_slice_cost_v3_static(const QpCircuit* circ, const QpDTable* dt, const uint8_t* A, int64_t B, int32_t Tp,
+                            int32_t ldq, double* out, void* stream);
+
 /* Gate-ordered cost of B sparse partitions (QP_ABSENT = qubit not in the slice's dict).
  * flags selects the reference variant:
  *   QP_V2  BFS_placer.py:202-239 == Random_placer.py:178-213

@@ -88,6 +88,9 @@ EXPORTS = {
     "qp_slice_cost_workspace": (C.c_size_t, [C.c_int32, C.c_int64]),
     "qp_slice_cost_v3": (C.c_int, [C.POINTER(QpCircuit), C.POINTER(QpDTable), C.c_void_p, C.c_int64, C.c_int32,
                                    C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "qp_static_scratch_bytes": (C.c_size_t, []),
+    "qp_slice_cost_v3_static": (C.c_int, [C.POINTER(QpCircuit), C.POINTER(QpDTable), C.c_void_p, C.c_int64, C.c_int32,
+                                          C.c_int32, C.c_void_p, C.c_void_p]),
     "qp_slice_cost_v2": (C.c_int, [C.POINTER(QpCircuit), C.POINTER(QpDTable), C.c_void_p, C.c_int64, C.c_int32,
                                    C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "qp_cost_matrix": (C.c_int, [C.c_int32, C.POINTER(QpCircuit), C.POINTER(QpDTable), C.c_int64, C.c_void_p,

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <limits>
 
@@ -1385,8 +1386,12 @@ extern "C" size_t qp_slice_cost_workspace(int32_t T, int64_t B) {
     return (size_t)(max_chunks * B) * sizeof(double) * 4 + 256 + 256 * 255 / 2 * sizeof(double) + 256;
 }
 
-extern "C" int qp_slice_cost_v3(const QpCircuit* circ, const QpDTable* dt, const uint8_t* A, int64_t B, int32_t Tp,
-                                int32_t ldq, double* out, void* workspace, size_t workspace_bytes, void* stream_) {
+namespace {
+
+// The dense cost path behind qp_slice_cost_v3 and qp_slice_cost_v3_static: every launch of it, with the
+// partial sums (and the symmetrised triangle of a large fp64 table) in `workspace`.
+int slice_cost_v3_impl(const QpCircuit* circ, const QpDTable* dt, const uint8_t* A, int64_t B, int32_t Tp,
+                       int32_t ldq, double* out, void* workspace, size_t workspace_bytes, void* stream_) {
     if (int rc = check_common("qp_slice_cost_v3", circ, dt, A, B, Tp, ldq, out)) return rc;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int32_t T = circ->T;
@@ -1581,6 +1586,52 @@ extern "C" int qp_slice_cost_v3(const QpCircuit* circ, const QpDTable* dt, const
     k_sum_chunks<<<(unsigned)((B + 255) / 256), 256, 0, stream>>>(p.partial, B, nchunks, out);
     HIP_TRY(hipGetLastError());
     return QP_OK;
+}
+
+// Scratch of qp_slice_cost_v3_static: lives in the code object, one copy per GPU the library runs on, for
+// as long as the process does.  The name below is a host-side handle, not a device address: host code
+// only ever uses the per-device address hipGetSymbolAddress returns for it.
+constexpr size_t kStaticScratchBytes = (size_t)QP_STATIC_SCRATCH_BYTES;
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
+constexpr int kMaxDevices = 64;
+std::atomic<void*> g_scratch_ptr[kMaxDevices];  // zero-initialised; set once per device
+
+// Device address of this GPU's copy of the scratch array (looked up on the first call on a device).
+int static_scratch(void** out) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) return qp::fail(QP_EINVAL, "qp_slice_cost_v3_static: device %d out of range", dev);
+    void* ptr = g_scratch_ptr[dev].load(std::memory_order_acquire);
+    if (!ptr) {
+        HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        if (!ptr) return qp::fail(QP_EHIP, "qp_slice_cost_v3_static: no address for the scratch array on device %d", dev);
+        g_scratch_ptr[dev].store(ptr, std::memory_order_release);  // every thread gets the same address for a device
+    }
+    *out = ptr;
+    return QP_OK;
+}
+
+}  // namespace
+
+extern "C" int qp_slice_cost_v3(const QpCircuit* circ, const QpDTable* dt, const uint8_t* A, int64_t B, int32_t Tp,
+                                int32_t ldq, double* out, void* workspace, size_t workspace_bytes, void* stream) {
+    return slice_cost_v3_impl(circ, dt, A, B, Tp, ldq, out, workspace, workspace_bytes, stream);
+}
+
+extern "C" size_t qp_static_scratch_bytes(void) { return kStaticScratchBytes; }
+
+extern "C" int qp_slice_cost_v3_static(const QpCircuit* circ, const QpDTable* dt, const uint8_t* A, int64_t B,
+                                       int32_t Tp, int32_t ldq, double* out, void* stream) {
+    void* ws = nullptr;
+    if (int rc = static_scratch(&ws)) return rc;
+    const int rc = slice_cost_v3_impl(circ, dt, A, B, Tp, ldq, out, ws, kStaticScratchBytes, stream);
+    if (rc == QP_ENOSPC)
+        return qp::fail(QP_ENOSPC,
+                        "qp_slice_cost_v3_static: %lld partitions x %d slices need more than the %zu bytes of static "
+                        "scratch (one double per partition and chunk of slices); split the batch or use qp_slice_cost_v3",
+                        (long long)B, circ->T, kStaticScratchBytes);
+    return rc;
 }
 
 extern "C" int qp_slice_cost_v2(const QpCircuit* circ, const QpDTable* dt, const uint8_t* A, int64_t B, int32_t Tp,

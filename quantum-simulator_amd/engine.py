@@ -210,6 +210,16 @@ class Engine:
                                      ws.data_ptr(), ws.numel(), _stream_ptr(self.device)))
         return out
 
+    def cost_v3_static(self, dc: DeviceCircuit, dt: DistanceTable, A, out, table="packed"):
+        """cost_v3 through the entry point that allocates nothing: ``out`` is required and the partial sums
+        live in the library's own static device array (raises QplaceError when the batch needs more of it
+        than there is)."""
+        B, Tp, ldq = self._check_partitions(dc, A)
+        tab = {"packed": dt.packed, "table": dt.table_only, "f64": dt.f64}[table]
+        check(lib().qp_slice_cost_v3_static(C.byref(dc.c), C.byref(tab), A.data_ptr(), B, Tp, ldq, out.data_ptr(),
+                                            _stream_ptr(self.device)))
+        return out
+
     def cost_v2(self, dc: DeviceCircuit, dt: DistanceTable, A, variant=QP_V2, out=None, table="packed"):
         """Gate-ordered cost (V1/V2/V4) of B sparse partitions (0xFF = absent)."""
         torch = _torch()

@@ -376,6 +376,19 @@ def test_cost_v3_full_size_against_c_oracle(gpu, integer):
     for b in range(B):
         want = c_oracle.cost_v3(gt, Q, A[b], D)
         assert _close(got[b], want, integer, nterms), (b, got[b], want)
+    if not integer:
+        # against the correctly rounded sum of the same terms the kernel stays inside 1e-12 however many
+        # terms there are (the wider bound above only covers the reference's own left-to-right rounding)
+        Dl = D.tolist()
+        worst_fsum = worst_seq = 0.0
+        for b in (0, 1, 2, 47):  # two rarely-moving and two mostly-moving partitions
+            terms = O.cost_v3_terms(ir.slices, ir.gate_q, ir.gate_mr, A[b].tolist(), Dl)
+            exact = math.fsum(terms)
+            assert abs(got[b] - exact) <= RTOL * exact, (b, got[b], exact)
+            worst_fsum = max(worst_fsum, abs(got[b] - exact) / exact)
+            worst_seq = max(worst_seq, abs(got[b] - c_oracle.cost_v3(gt, Q, A[b], D)) / exact)
+        print(f"\nfull-size fp64 cost: max relative deviation from fsum {worst_fsum:.3e}, "
+              f"from the sequential sum {worst_seq:.3e} ({len(terms)} terms)")
     # size-independent property: the cost is additive over a split of the timeline when the second
     # part starts with a repeated row (no movement is charged for rows 0 and 1 of either part)
     assert got.tobytes() == eng.cost_v3(dc, dt, torch.from_numpy(A).to(dev)).cpu().numpy().tobytes()

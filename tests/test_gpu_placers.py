@@ -187,6 +187,25 @@ def test_place_batch_lockstep(name, pname):
         assert (got[b] == np.array(want, np.uint8)).all(), (pname, b)
 
 
+@pytest.mark.parametrize("name", ["qft63_torus8x8_u", "qft63_torus8x8_i"])
+@pytest.mark.parametrize("pname", ["HQA", "TRHQA", "GTRHQA"])
+def test_place_batch_large_torus_case(name, pname):
+    """The large shipped configuration (qft_n63 on the 8x8 torus, capacity 2): a batch of 8 repeats gives
+    the reference's own partition in every instance, and its cost."""
+    from quantum_simulator_amd.placers import PLACERS
+    gc = load_case(name)
+    circ, arch = case_circuit(gc), case_arch(gc)
+    placer = PLACERS[pname]()
+    rows = placer.place_batch(circ, arch, B=8)
+    want = gc.part(pname)
+    for b in range(8):
+        assert (rows[b][:, :gc.Q] == want).all(), (pname, b)
+    _, costs = placer.run_repeats(circ, arch, 8)
+    ctx = placer._context(circ, arch)
+    for c in costs:
+        assert _cost_ok(c, gc.cost(pname), name.endswith("_i"), ctx.ir.nE + ctx.ir.T * gc.Q)
+
+
 GTR_SHAPES = [  # Q, T, C, cap, instances, disconnected graph, integer edge weights
     (40, 30, 8, 6, 4, False, False), (200, 20, 32, 8, 5, False, False), (33, 12, 5, 8, 3, False, False),
     (64, 15, 16, 4, 4, False, False), (48, 10, 8, 6, 3, True, False), (300, 8, 64, 6, 3, True, False),

@@ -227,3 +227,149 @@ def test_anneal_not_worse_than_plain_cpu_annealing(gpu):
     X, _ = dq.anneal(128, sweeps, seed=3)
     gpu_best = int(dq.energy(X).min())
     assert gpu_best <= cpu_best, (gpu_best, cpu_best)
+
+
+def _energy_of(dq, qm, torch, dev, states):
+    """Energies of a few states through the MFMA path (batch padded to 128 replicas)."""
+    X = np.zeros((128, qm.Npad), np.int8)
+    X[:len(states)] = states
+    return dq.energy(torch.from_numpy(X).to(dev)).cpu().numpy()[:len(states)]
+
+
+def test_three_qubit_gate_couples_all_pairs(gpu):
+    """A gate on three qubits makes all three pairs interact (Qubo_placer.py:58-66): every qubit has degree 2.
+    Hand-derived energies: all three on one core with three slack bits set: 0.  Two on core 0 (two slack
+    bits), one on core 1 (one slack bit): core 0 contributes 10 * (2 + 2 - 2 * 1), core 1 10 * 2: 40.
+    One qubit per core on three cores: 10 * 6 = 60."""
+    torch, dev = gpu
+    from quantum_simulator_amd.qubo import DeviceQubo, QuboModel
+    from quantum_simulator_amd.timeslices import CircuitIR
+    ir = CircuitIR(3, [(0, 1, 2)], [False])
+    names = ["q[0]", "q[1]", "q[2]"]
+    H = np.array([[0, 1, 2], [1, 0, 1], [2, 1, 0]])
+    qm = QuboModel(ir, 3, 3, H, names)
+    assert qm.inter[0] == [(0, 1), (0, 2), (1, 2)] and qm.deg[0].tolist() == [2, 2, 2]
+    dq = DeviceQubo(qm, dev)
+    rows = [[[0, 0, 0]], [[0, 0, 1]], [[0, 1, 2]]]
+    states = [qm.state_from_rows(r) for r in rows]
+    e = _energy_of(dq, qm, torch, dev, states)
+    assert e.tolist() == [0, 40, 60]
+    for s, want in zip(states, (0, 40, 60)):
+        assert _oracle_energy(qm, names, s)[0] == want
+
+
+def test_long_moves_split_into_int8_layers(gpu):
+    """A coupling of 10 * hops above 127 does not fit one int8 matrix: on a line of 15 cores a qubit that is
+    on core 0 in slice 0 and on core 14 in slice 1 costs 10 * 14 = 140 and nothing else (one-hot, slack bit
+    set); moving it to core 13 costs 130, to core 12 120 (one layer suffices there)."""
+    torch, dev = gpu
+    from quantum_simulator_amd.engine import hops
+    from quantum_simulator_amd.qubo import DeviceQubo, QuboModel
+    from quantum_simulator_amd.timeslices import CircuitIR
+    ir = CircuitIR(1, [(0,), (0,)], [False, False])
+    assert ir.T == 2
+    C = 15
+    H = hops(C, list(range(C - 1)), list(range(1, C)))
+    assert H[0, 14] == 14
+    qm = QuboModel(ir, C, 1, H, ["q[0]"])
+    assert len(qm.move_layers(0)) == 2
+    dq = DeviceQubo(qm, dev)
+    states = [qm.state_from_rows([[0], [c]]) for c in (14, 13, 12, 0)]
+    e = _energy_of(dq, qm, torch, dev, states)
+    assert e.tolist() == [140, 130, 120, 0]
+    for s, want in zip(states, (140, 130, 120, 0)):
+        assert _oracle_energy(qm, ["q[0]"], s)[0] == want
+    # the local field of the slice-1 bit on core 14 sees the slice-0 bit through both layers
+    X = np.zeros((128, qm.Npad), np.int8)
+    X[0] = states[0]
+    F = dq.fields(torch.from_numpy(X).to(dev)).cpu().numpy()
+    assert F[qm.var_x(1, 14, 0), 0] == 140 - 8  # 10 * 14 from the move, -8 from the core's slack bit
+
+
+def test_active_qubits_are_ordered_by_name(gpu):
+    """Active qubits are sorted by str(qubit) (Qubo_placer.py:48): 'q[10]' comes before 'q[2]', so in a slice
+    with a gate on q[2], q[10] variable 0 is q[10]; the coupling to the next slice follows the qubit, not the
+    position.  Slice 0: gate (q[2], q[10]), q[10] on core 0 and q[2] on core 1 (one slack bit each): the
+    Laplacian term is 10 * (1 + 1) = 20.  Slice 1: gate (q[2], q[3]), both on core 1: 0.  q[2] stays on core
+    1: no move.  Total 20 (coupling position 0 of slice 0 with position 0 of slice 1 would give 30)."""
+    torch, dev = gpu
+    from quantum_simulator_amd.qubo import DeviceQubo, QuboModel
+    from quantum_simulator_amd.timeslices import CircuitIR
+    names = [f"q[{i}]" for i in range(11)]
+    ir = CircuitIR(11, [(2, 10), (2, 3)], [False, False])
+    assert ir.T == 2
+    qm = QuboModel(ir, 2, 2, np.array([[0, 1], [1, 0]]), names)
+    assert qm.act == [[10, 2], [2, 3]]
+    assert qm.nxt[0].tolist() == [-1, 0]
+    dq = DeviceQubo(qm, dev)
+    row0 = [None] * 11
+    row0[10], row0[2] = 0, 1
+    row1 = [None] * 11
+    row1[2], row1[3] = 1, 1
+    s = qm.state_from_rows([row0, row1])
+    assert s[qm.var_x(0, 0, 0)] == 1 and s[qm.var_x(0, 1, 1)] == 1  # q[10] is variable 0 of slice 0
+    e = _energy_of(dq, qm, torch, dev, [s])
+    assert e.tolist() == [20]
+    assert _oracle_energy(qm, names, s)[0] == 20
+    rows = qm.decode(s)
+    assert rows[0][10] == 0 and rows[0][2] == 1 and rows[1][2] == 1 and rows[1][3] == 1
+    # q[2] moved to core 0 in slice 1 (q[3] with it): one hop, +10
+    row1b = [None] * 11
+    row1b[2], row1b[3] = 0, 0
+    assert _energy_of(dq, qm, torch, dev, [qm.state_from_rows([row0, row1b])]).tolist() == [30]
+
+
+def test_benchmark_size_model(gpu):
+    """The QUBO benchmark's own model: 256-qubit layered circuit x 8 slices on a 4x4 mesh, capacity 20
+    (35 328 variables, 35 row tiles per slice), 4096 replicas, so that the 128 x 256 tile and the launch
+    order of the replica tiles are the ones checked.  Energies of the all-zero state, the block placement,
+    random states and the best annealed state equal the restated objective; fields equal energy differences
+    of single flips; the annealer's summed dE equals the energy difference over 50 sweeps."""
+    torch, dev = gpu
+    from quantum_simulator_amd import layered_gate_arrays
+    from quantum_simulator_amd.engine import hops
+    from quantum_simulator_amd.multicore import build_topology, graph_tables
+    from quantum_simulator_amd.qubo import DeviceQubo, QuboModel
+    from quantum_simulator_amd.timeslices import CircuitIR
+    Q, T, cap, R = 256, 8, 20, 4096
+    q0, q1, _ = layered_gate_arrays(Q, T, 0.5, seed=4242)
+    ir = CircuitIR.from_gate_tables(Q, q0, q1)
+    nodes, eu, ev, _ = graph_tables(build_topology("mesh", 4, 4))
+    names = [f"q[{i}]" for i in range(Q)]
+    qm = QuboModel(ir, len(nodes), cap, hops(len(nodes), eu, ev), names)
+    assert qm.N == 35328 and qm.Npad == 8 * 4480
+    dq = DeviceQubo(qm, dev)
+    rng = np.random.default_rng(7)
+    real = np.zeros(qm.Npad, bool)
+    for t in range(qm.T):
+        real[qm.off[t]:qm.off[t] + qm.Nt[t]] = True
+    X0, d0 = dq.anneal(R, 0, seed=5)          # the annealer's random start
+    e0 = dq.energy(X0)
+    X1, d1 = dq.anneal(R, 50, seed=5)
+    e1 = dq.energy(X1)
+    assert torch.equal(e1 - e0, d1), "summed accepted dE must equal the exact energy difference"
+    X = X1.clone()
+    rows0 = [[(qm.pos[t][q] // cap if q in qm.pos[t] else None) for q in range(Q)] for t in range(qm.T)]
+    block = qm.state_from_rows(rows0)
+    X[0] = 0
+    X[1] = torch.from_numpy(block).to(dev)
+    dense = np.zeros(qm.Npad, np.int8)
+    dense[real] = rng.integers(0, 2, size=int(real.sum()))
+    X[2] = torch.from_numpy(dense).to(dev)
+    best = int(e1[3:].argmin()) + 3
+    check = [0, 1, 2, best, 127, 128, 255, 256, 2049, R - 1]  # both halves of a 256-replica tile, several tiles
+    e = dq.energy(X).cpu().numpy()
+    Xh = X.cpu().numpy()
+    for r in check:
+        want, _ = _oracle_energy(qm, names, Xh[r])
+        assert e[r] == want, (r, e[r], want)
+    assert e[0] == qm.const == 4 * int(qm.n.sum())
+    F = dq.fields(X).cpu().numpy()
+    a = qm.linear()
+    for r in (2, best, R - 1):
+        base, _ = _oracle_energy(qm, names, Xh[r])
+        for v in rng.choice(np.flatnonzero(real), size=6, replace=False):
+            s2 = Xh[r].copy()
+            s2[v] ^= 1
+            want, _ = _oracle_energy(qm, names, s2)
+            assert want - base == (1 - 2 * int(Xh[r, v])) * (a[v] + F[v, r]), (r, v)

@@ -1,0 +1,77 @@
+"""qp_slice_cost_v3_static (the entry point that allocates nothing) against qp_slice_cost_v3, through the
+C ABI, bit for bit: two calls in a row on the same GPU, the second with a smaller input, so that what the
+first call left in the static scratch array cannot leak into the second; then the size limit."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(torch, engine, dev, Q, T, ncores, B, integer, seed):
+    from quantum_simulator_amd import layered_gate_arrays
+    from quantum_simulator_amd.timeslices import CircuitIR
+    rng = np.random.default_rng(seed)
+    q0, q1, _ = layered_gate_arrays(Q, T, 0.5, seed=seed)
+    keep = rng.random(len(q0)) > 0.2
+    ir = CircuitIR.from_gate_tables(Q, q0[keep], q1[keep])
+    eu = list(range(ncores))
+    ev = [(i + 1) % ncores for i in range(ncores)]
+    w = rng.integers(1, 5, size=ncores).astype(float) if integer else rng.uniform(1, 3, size=ncores)
+    D = engine.apsp(ncores, eu, ev, w)
+    dc, dt = engine.DeviceCircuit(ir, dev), engine.DistanceTable(D, dev)
+    A = torch.from_numpy(rng.integers(0, ncores, size=(B, ir.T, dc.ldq), dtype=np.uint8)).to(dev)
+    return dc, dt, A
+
+
+# (Q, T, cores, B, integer weights): the fp64 pair-count path (which also keeps its symmetrised table in
+# the scratch), the LDS-table paths for short and 1 KB rows, rows longer than 1 KB; each followed by a
+# smaller problem of another kind
+CASES = [
+    [(1024, 60, 256, 9, False), (1024, 7, 200, 2, False)],
+    [(1024, 40, 64, 6, True), (40, 9, 8, 3, True)],
+    [(2048, 12, 100, 4, False), (300, 5, 16, 1, False)],
+    [(500, 33, 256, 5, False), (1024, 3, 256, 1, True)],
+]
+
+
+@pytest.mark.parametrize("pair", CASES)
+def test_static_entry_point_matches_workspace_entry_point(pair):
+    import torch
+    from quantum_simulator_amd import engine
+    from quantum_simulator_amd._lib import lib
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need an MI355X; none is visible")
+    dev = torch.device("cuda", 0)
+    eng = engine.Engine(dev)
+    assert lib().qp_static_scratch_bytes() == 4 << 20
+    for k, (Q, T, ncores, B, integer) in enumerate(pair):
+        dc, dt, A = _setup(torch, engine, dev, Q, T, ncores, B, integer, seed=31 * Q + T + k)
+        for table in ("packed", "table"):
+            want = eng.cost_v3(dc, dt, A, table=table).cpu().numpy()
+            out = torch.full((B,), -1.0, dtype=torch.float64, device=dev)
+            got = eng.cost_v3_static(dc, dt, A, out, table=table).cpu().numpy()
+            assert got.tobytes() == want.tobytes(), (k, table, got, want)
+            assert np.isfinite(got).all() and (got >= 0).all()
+
+
+def test_static_entry_point_refuses_what_does_not_fit():
+    import torch
+    from quantum_simulator_amd import engine
+    from quantum_simulator_amd._lib import QplaceError, lib
+    dev = torch.device("cuda", 0)
+    eng = engine.Engine(dev)
+    # 40 qubits: rows of 48 bytes go 21 to a wave step and 84 to a chunk, one partial sum per partition and
+    # chunk; enough partitions that the sums outgrow the 4 MiB the library holds
+    dc, dt, _ = _setup(torch, engine, dev, 40, 900, 8, 1, True, seed=5)
+    nchunks = (dc.ir.T + 83) // 84
+    B = (4 << 20) // 8 // nchunks + 1000
+    A = torch.zeros((B, dc.ir.T, dc.ldq), dtype=torch.uint8, device=dev)
+    out = torch.empty(B, dtype=torch.float64, device=dev)
+    with pytest.raises(QplaceError) as err:
+        eng.cost_v3_static(dc, dt, A, out)
+    assert err.value.code == -3 and "static" in str(err.value)
+    # the same batch in two halves fits
+    half = eng.cost_v3_static(dc, dt, A[:B // 2], out[:B // 2]).cpu().numpy()
+    assert (half == 0.0).all()
