@@ -485,22 +485,57 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_row(V3Args p) {
 
 // fp64 table too large for LDS (more than about 134 cores), symmetric up to rounding: instead of looking
 // distances up, count how often every unordered pair of cores occurs and multiply by the table once per
-// item.  The counters (one uint32 per pair a < b, at b * (b - 1) / 2 + a: 127.5 KB for 256 cores) fit in
-// LDS where the table does not.  One workgroup = one item (rows r0..r1 of one partition); its waves take
-// consecutive runs of those rows, feed the shared counters with LDS atomics (only lanes whose pair has
-// two different cores issue one), and after a barrier the whole workgroup forms sum(count * Dsym) over
-// the table's triangle in a fixed order, zeroing the counters as it goes.  Dsym[a][b] is the mean of
-// D[a][b] and D[b][a] (written by k_sym_triangle), so what is lost against summing the directed entries
-// is |count(a->b) - count(b->a)| * |D[a][b] - D[b][a]| / 2 per pair.
-__global__ void k_sym_triangle(const double* D, int32_t C, double* tri) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n = C * (C - 1) / 2;
-    if (k >= n) return;
-    int b = (int)((1.0 + sqrt(1.0 + 8.0 * (double)k)) * 0.5);  // largest b with b * (b - 1) / 2 <= k
-    while (b * (b - 1) / 2 > k) --b;
-    while ((b + 1) * b / 2 <= k) ++b;
-    const int a = k - b * (b - 1) / 2;
-    tri[k] = (D[(size_t)a * C + b] + D[(size_t)b * C + a]) * 0.5;
+// item.  The counters (one uint32 per unordered pair) fit in LDS where the table does not.  One workgroup =
+// one item (rows r0..r1 of one partition); its waves take consecutive runs of those rows, feed the shared
+// counters with LDS atomics, and after a barrier the whole workgroup forms sum(count * Dsym) over all slots
+// in a fixed order, zeroing the counters as it goes.  Dsym is the mean of D[a][b] and D[b][a] (written by
+// k_sym_fold), so what is lost against summing the directed entries is
+// |count(a->b) - count(b->a)| * |D[a][b] - D[b][a]| / 2 per pair.
+//
+// Slot of the pair hi >= lo: the triangle (diagonal included) folded into a 128 x 256 rectangle,
+//   key = hi << 8 | lo;   slot = key & 0x7FFF when hi >= 128,  ~key & 0x7FFF when hi < 128
+// (row hi - 128 holds columns 0..hi, row 127 - hi the columns 255 - hi..255; the two diagonal entries that
+// share a slot are never summed: the table is zero there).  Two pairs are handled per register: the keys
+// p << 8 | c and c << 8 | p of both come out of one v_perm_b32 each, their packed 16-bit maximum is
+// hi << 8 | lo, an arithmetic shift by 15 and an exclusive-nor fold it (bit 15 of the result is always set,
+// which the address constant absorbs), and one v_mad_u32_u16 per pair turns a half into an LDS address.
+constexpr int kPairSlots = 128 * 256;
+
+__global__ void k_sym_fold(const double* D, int32_t C, double* fold) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= kPairSlots) return;
+    const int r = idx >> 8, col = idx & 255;
+    int hi, lo;
+    if (col <= 128 + r) {
+        hi = 128 + r;
+        lo = col;
+    } else {
+        hi = 127 - r;
+        lo = 255 - col;
+    }
+    fold[idx] = (hi < C && lo < hi) ? (D[(size_t)lo * C + hi] + D[(size_t)hi * C + lo]) * 0.5 : 0.0;
+}
+
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+
+// hi << 8 | lo of two (a, b) pairs, folded: k = a << 8 | b and s = b << 8 | a in each 16-bit half
+__device__ inline uint32_t fold_keys(uint32_t k, uint32_t s) {
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    typedef short i16x2 __attribute__((ext_vector_type(2)));
+    const u16x2 m = __builtin_elementwise_max(__builtin_bit_cast(u16x2, k), __builtin_bit_cast(u16x2, s));
+    const i16x2 t = __builtin_bit_cast(i16x2, m) >> 15;
+    return ~(__builtin_bit_cast(uint32_t, m) ^ __builtin_bit_cast(uint32_t, t));
+}
+
+// One count for each of the two pairs whose folded keys are the halves of x.  base = LDS address of the
+// counters minus 0x20000 (bit 15 of a folded key is set: 0x8000 * 4).
+__device__ inline void count_keys(uint32_t x, uint32_t base) {
+    uint32_t a0, a1;
+    asm("v_mad_u32_u16 %0, %1, 4, %2 op_sel:[0,0,0,0]" : "=v"(a0) : "v"(x), "s"(base));
+    asm("v_mad_u32_u16 %0, %1, 4, %2 op_sel:[1,0,0,0]" : "=v"(a1) : "v"(x), "s"(base));
+    __hip_atomic_fetch_add((lds_u32*)(uintptr_t)a0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add((lds_u32*)(uintptr_t)a1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 template <int AHEAD = kV3Ahead>
@@ -509,14 +544,14 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_pairs(V3Args p) {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int ldq = p.ldq;
-    // LDS: strips, the workgroup reduction, then the counters last, so that a pair index made from core
-    // ids >= C (the caller's error) lands past the allocation, where the hardware drops the access
-    uint8_t* strip = smem + (size_t)wave * ldq;
-    double* red = reinterpret_cast<double*>(smem + (size_t)kV3Waves * ldq);
-    uint32_t* cnt = reinterpret_cast<uint32_t*>(red + kV3Waves);
-    const int ntri = p.C * (p.C - 1) / 2;
-    const double* tri = static_cast<const double*>(p.table);
-    for (int k = threadIdx.x; k < ntri; k += kV3Threads) cnt[k] = 0;
+    // LDS: the counters, the waves' strips, the workgroup reduction.  Every byte a core id can take has a
+    // slot, so ids >= C (the caller's error) count into slots whose table entry is zero.
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(smem);
+    uint8_t* strip = smem + (size_t)kPairSlots * 4 + (size_t)wave * ldq;
+    double* red = reinterpret_cast<double*>(smem + (size_t)kPairSlots * 4 + (size_t)kV3Waves * ldq);
+    const uint32_t cbase = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_u8*)smem - 0x20000u);
+    const double* fold = static_cast<const double*>(p.table);
+    for (int k = threadIdx.x; k < kPairSlots; k += kV3Threads) cnt[k] = 0;
     __syncthreads();
 
     const bool lane_on = lane * 16 < ldq;
@@ -527,21 +562,14 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_pairs(V3Args p) {
         const int nb = min(4, max(0, nvalid_row - 4 * w));
         keep[w] = nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u);
     }
-    auto count = [&](uint32_t a, uint32_t b) {
-        if (a != b) {
-            const uint32_t hi = max(a, b), lo = min(a, b);
-            // byte offset 4 * (hi * (hi - 1) / 2 + lo), formed without the shift pair a division would cost
-            // an LDS-qualified pointer: the compiler then knows the update cannot touch the (global) slice
-            // pointers and keeps reading those through the scalar cache
-            typedef __attribute__((address_space(3))) uint8_t lds_u8;
-            typedef __attribute__((address_space(3))) uint32_t lds_u32;
-            lds_u32* slot = (lds_u32*)((lds_u8*)cnt + (__umul24(hi, hi - 1u) * 2u + lo * 4u));
-            __hip_atomic_fetch_add(slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-    };
+    // the four (previous, current) pairs of a dword; a qubit that stayed counts into a diagonal slot
     auto count4 = [&](uint32_t pf, uint32_t cf) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) count((pf >> (8 * j)) & 0xFFu, (cf >> (8 * j)) & 0xFFu);
+        count_keys(fold_keys(__builtin_amdgcn_perm(pf, cf, 0x05010400u), __builtin_amdgcn_perm(cf, pf, 0x05010400u)), cbase);
+        count_keys(fold_keys(__builtin_amdgcn_perm(pf, cf, 0x07030602u), __builtin_amdgcn_perm(cf, pf, 0x07030602u)), cbase);
+    };
+    // two gates: the cores of their first qubits in the halves of u2, of their second qubits in v2
+    auto count_gates2 = [&](uint32_t u2, uint32_t v2) {
+        if (u2 != v2) count_keys(fold_keys(u2 << 8 | v2, v2 << 8 | u2), cbase);
     };
 
     for (int64_t it = blockIdx.x; it < p.nitems; it += gridDim.x) {
@@ -615,17 +643,19 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_pairs(V3Args p) {
                     av[c] = strip[g >> 16];
                 }
                 const uint32_t c0 = cur.x & keep[0], c1 = cur.y & keep[1], c2 = cur.z & keep[2], c3 = cur.w & keep[3];
-                if (row >= 2) {  // movement is charged from row 2 on
+                if (row >= 2) {  // movement is charged from row 2 on; a dword of qubits that all stayed is skipped
                     if (c0 != p0) count4(p0, c0);
                     if (c1 != p1) count4(p1, c1);
                     if (c2 != p2) count4(p2, c2);
                     if (c3 != p3) count4(p3, c3);
                 }
-#pragma unroll
-                for (int c = 0; c < kRowEdgeChunks; ++c) count(au[c], av[c]);
+                static_assert(kRowEdgeChunks == 4, "the first four gate chunks of a row are counted two to a register");
+                count_gates2(au[0] | au[1] << 16, av[0] | av[1] << 16);
+                count_gates2(au[2] | au[3] << 16, av[2] | av[3] << 16);
                 for (int c = kRowEdgeChunks; c < nch; ++c) {
                     const uint32_t g = sched_lane[s0 + c * kWave];
-                    count(strip[g & 0xFFFFu], strip[g >> 16]);
+                    const uint32_t u = strip[g & 0xFFFFu], v = strip[g >> 16];
+                    count_gates2(u, v);  // the upper halves are the pair (0, 0): a diagonal slot
                 }
                 p0 = c0;
                 p1 = c1;
@@ -647,14 +677,14 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_pairs(V3Args p) {
         // table entries are loaded whether or not the pair occurred (coalesced, cache-resident), eight at a
         // time, so the loop is not a chain of load latencies; an unused entry may be infinite: select, not multiply
         double acc = 0.0;
-        for (int k0 = threadIdx.x; k0 < ntri; k0 += 8 * kV3Threads) {
+        static_assert(kPairSlots % (8 * kV3Threads) == 0, "whole batches of eight slots per thread");
+        for (int k0 = threadIdx.x; k0 < kPairSlots; k0 += 8 * kV3Threads) {
             double d[8];
             uint32_t n[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int k = k0 + j * kV3Threads;
-                d[j] = tri[min(k, ntri - 1)];
-                n[j] = k < ntri ? cnt[k] : 0u;
+                d[j] = fold[k0 + j * kV3Threads];
+                n[j] = cnt[k0 + j * kV3Threads];
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -1382,8 +1412,8 @@ extern "C" size_t qp_slice_cost_workspace(int32_t T, int64_t B) {
     if (T <= 0 || B <= 0) return 16;
     // one double per (chunk, partition); chunks are never shorter than 16 rows unless T is
     const int64_t max_chunks = (T + 15) / 16 + 1;
-    // up to four table-band passes; room for the symmetrised triangle of a 256-core table
-    return (size_t)(max_chunks * B) * sizeof(double) * 4 + 256 + 256 * 255 / 2 * sizeof(double) + 256;
+    // up to four table-band passes; room for the symmetrised, folded triangle of a 256-core table
+    return (size_t)(max_chunks * B) * sizeof(double) * 4 + 256 + 128 * 256 * sizeof(double) + 256;
 }
 
 namespace {
@@ -1493,9 +1523,8 @@ int slice_cost_v3_impl(const QpCircuit* circ, const QpDTable* dt, const uint8_t*
         }
         if (rowpath && mode == kTabGlobal && dt->kind == QP_DT_F64 && dt->symmetric && dt->C >= 2) {
             // fp64 table too big for LDS but symmetric up to rounding: count core pairs in LDS, one pass
-            const int ntri = dt->C * (dt->C - 1) / 2;
-            const size_t tri_bytes = ((size_t)ntri * sizeof(double) + 255) & ~(size_t)255;
-            const size_t pairs_lds = (size_t)kV3Waves * ldq + kV3Waves * sizeof(double) + (size_t)ntri * sizeof(uint32_t);
+            const size_t fold_bytes = (size_t)kPairSlots * sizeof(double);
+            const size_t pairs_lds = (size_t)kPairSlots * sizeof(uint32_t) + (size_t)kV3Waves * ldq + kV3Waves * sizeof(double);
             // whole workgroups take an item; rows in runs of at least 4 per wave, about 8 items per workgroup
             V3Args q = p;
             const int64_t want = ((int64_t)T * B + (int64_t)cus * 8 - 1) / ((int64_t)cus * 8);
@@ -1503,11 +1532,11 @@ int slice_cost_v3_impl(const QpCircuit* circ, const QpDTable* dt, const uint8_t*
             const int32_t pchunks = (T + q.rows_per_item - 1) / q.rows_per_item;
             q.nitems = (int64_t)pchunks * B;
             const size_t part_bytes = ((size_t)q.nitems * sizeof(double) + 255) & ~(size_t)255;
-            if (pairs_lds <= (size_t)kLdsBytes && workspace_bytes >= part_bytes + tri_bytes) {
-                double* tri = reinterpret_cast<double*>(static_cast<uint8_t*>(workspace) + part_bytes);
-                k_sym_triangle<<<(unsigned)((ntri + 255) / 256), 256, 0, stream>>>(static_cast<const double*>(dt->table), dt->C, tri);
+            if (pairs_lds <= (size_t)kLdsBytes && workspace_bytes >= part_bytes + fold_bytes) {
+                double* fold = reinterpret_cast<double*>(static_cast<uint8_t*>(workspace) + part_bytes);
+                k_sym_fold<<<kPairSlots / 256, 256, 0, stream>>>(static_cast<const double*>(dt->table), dt->C, fold);
                 HIP_TRY(hipGetLastError());
-                q.table = tri;
+                q.table = fold;
                 kern = k_cost_v3_pairs<kV3Ahead>;
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pairs_lds));
                 const unsigned pgrid = (unsigned)std::min<int64_t>(cus, q.nitems);
