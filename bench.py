@@ -149,8 +149,7 @@ def bench_shipped(dev):
     """The reference's shipped circuits (gate tables from tests/golden; the QASM files themselves do not travel):
     batches of whole placements + their costs, as the driver runs a config's repeats.  cfg2 = qft_n18 on the 4x4
     mesh, cfg3 = qft_n63 on the 8x8 torus (one GPU's share of 64 repeats is 8; 64 are run)."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from conftest import case_arch, case_circuit, load_case
+    from quantum_simulator_amd.golden import case_arch, case_circuit, load_case
     from quantum_simulator_amd.placers import PLACERS
     rows = []
     for cfg, name, B in (("cfg2", "qft18_mesh4x4_u", 256), ("cfg3", "qft63_torus8x8_u", 64)):

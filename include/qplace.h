@@ -98,7 +98,7 @@ typedef struct QpGridMetric {
 typedef struct QpDTable {
     int32_t kind;
     int32_t C;
-    const void* table; /* dev, C*C entries, row-major, zero diagonal */
+    const void* table; /* dev, exactly C*C entries, row-major, zero diagonal; 16-byte aligned */
     QpGridMetric grid; /* all zero when unused; only consulted for QP_DT_U16 */
     int32_t symmetric; /* QP_DT_F64 only: non-zero = qp_dtable_symmetric accepted the matrix.  The dense cost
                           kernel may then use (D[a][b] + D[b][a]) / 2 for both directions of a pair, which is

@@ -48,13 +48,16 @@ __device__ inline uint4 load_row16(const uint8_t* ptr) {
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
-// Copies the distance table into LDS (16 bytes per thread per step; the device buffer is padded to a
-// multiple of 16 bytes) and returns the padded size.
+// Copies the distance table (16-byte aligned, exactly `bytes` long) into LDS, 16 bytes per thread per
+// step and the last few bytes one by one, and returns the size rounded up to 16.
 __device__ inline uint32_t stage_table(uint8_t* smem, const void* table, uint32_t bytes) {
     const uint32_t padded = (bytes + 15u) & ~15u;
     const uint4* src = static_cast<const uint4*>(table);
     uint4* dst = reinterpret_cast<uint4*>(smem);
-    for (uint32_t k = threadIdx.x; k < padded / 16; k += blockDim.x) dst[k] = src[k];
+    for (uint32_t k = threadIdx.x; k < bytes / 16; k += blockDim.x) dst[k] = src[k];
+    const uint32_t done = bytes & ~15u;
+    if (threadIdx.x < padded - done)
+        smem[done + threadIdx.x] = done + threadIdx.x < bytes ? static_cast<const uint8_t*>(table)[done + threadIdx.x] : uint8_t(0);
     __syncthreads();
     return padded;
 }
@@ -1402,6 +1405,8 @@ int check_common(const char* fn, const QpCircuit* circ, const QpDTable* dt, cons
     if (ldq < circ->Q || ldq % 16 != 0) return qp::fail(QP_EINVAL, "%s: ldq must be >= Q and a multiple of 16", fn);
     if (dt->C <= 0 || dt->C > 256 || !dt->table) return qp::fail(QP_EINVAL, "%s: bad distance table", fn);
     if (dt->kind != QP_DT_F64 && dt->kind != QP_DT_U16) return qp::fail(QP_EINVAL, "%s: unknown table kind", fn);
+    if (reinterpret_cast<uintptr_t>(dt->table) % 16 != 0) return qp::fail(QP_EINVAL, "%s: the distance table must be 16-byte aligned", fn);
+    if (reinterpret_cast<uintptr_t>(A) % 16 != 0) return qp::fail(QP_EINVAL, "%s: the partitions must be 16-byte aligned", fn);
     if (Tp <= 0) return qp::fail(QP_EINVAL, "%s: Tp must be positive", fn);
     return QP_OK;
 }

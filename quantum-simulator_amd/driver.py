@@ -25,6 +25,7 @@ import csv
 import math
 import os
 import random
+import re
 import time
 import zlib
 
@@ -35,48 +36,57 @@ REQUIRED = ["mode", "topology", "num_cores_x", "num_cores_y", "ncm_qubits", "ncp
             "circuit_folders", "placers", "repeats", "out_csv", "plot_file"]
 
 
-def _value(text: str):
-    v = text.strip()
-    try:
-        return int(v)
-    except ValueError:
-        pass
-    if "," in v:
-        parts = [p.strip() for p in v.split(",") if p.strip()]
-        try:
-            nums = [float(p) for p in parts]
-            return nums if len(nums) > 1 else nums[0]
-        except ValueError:
-            return parts
-    return v
+_NUMBER = re.compile(r"[+-]?(\d+(\.\d*)?|\.\d+)([eE][+-]?\d+)?$")
+
+
+def _scalar_or_list(text: str):
+    """A config value: an int when it reads as one, else a comma list (all floats when every item is a
+    number, a single float for a one-item list, otherwise the stripped strings), else the string."""
+    text = text.strip()
+    if re.fullmatch(r"[+-]?\d+", text):
+        return int(text)
+    if "," not in text:
+        return text
+    items = [piece.strip() for piece in text.split(",")]
+    items = [piece for piece in items if piece]
+    if not all(_NUMBER.match(piece) or piece.lower() in ("inf", "nan", "+inf", "-inf", "infinity") for piece in items):
+        return items
+    numbers = [float(piece) for piece in items]
+    return numbers[0] if len(numbers) == 1 else numbers
+
+
+def _as_name_list(value):
+    pieces = value if isinstance(value, list) else str(value).split(",")
+    return [str(piece).strip() for piece in pieces if str(piece).strip()]
 
 
 def parse_config_file(path: str) -> dict:
-    assert os.path.exists(path), f"Config file not found: {path}"
+    """config_parser.py:20-84: same keys, same checks in the same order (mode and topology first, then the
+    rest), same normalisation of the weight range, the folder list and the placer list."""
+    if not os.path.exists(path):
+        raise AssertionError(f"Config file not found: {path}")
     cfg = {}
-    with open(path) as f:
-        for line in f:
-            line = line.strip()
-            if not line or line.startswith("#") or "=" not in line:
-                continue
-            k, v = line.split("=", 1)
-            cfg[k.strip()] = _value(v)
-    for key in REQUIRED[:2]:
-        assert key in cfg, f"Missing required parameter: {key}"
-    assert cfg["mode"] in ["simulate"], "mode must be 'simulate' or ..."
-    assert cfg["topology"] in TOPOLOGY_NAMES, "Invalid topology, must be one of mesh, line, star, tree, torus, complete"
-    for key in REQUIRED[2:]:
-        assert key in cfg, f"Missing required parameter: {key}"
-    ewr = cfg["edge_weight_range"]
-    if isinstance(ewr, list) and len(ewr) >= 2:
-        cfg["edge_weight_range"] = (float(ewr[0]), float(ewr[1]))
-    else:
+    with open(path) as handle:
+        for raw in handle:
+            entry = raw.split("#", 1)[0] if raw.lstrip().startswith("#") else raw
+            key, sep, value = entry.partition("=")
+            if sep and key.strip():
+                cfg[key.strip()] = _scalar_or_list(value)
+    checks = {"mode": (["simulate"], "mode must be 'simulate' or ..."),
+              "topology": (TOPOLOGY_NAMES, "Invalid topology, must be one of " + ", ".join(TOPOLOGY_NAMES))}
+    for position, key in enumerate(REQUIRED):
+        if position == len(checks):  # the two checked keys come first in REQUIRED
+            for name, (allowed, message) in checks.items():
+                if cfg[name] not in allowed:
+                    raise AssertionError(message)
+        if key not in cfg:
+            raise AssertionError(f"Missing required parameter: {key}")
+    span = cfg["edge_weight_range"]
+    if not (isinstance(span, list) and len(span) >= 2):
         raise AssertionError("edge_weight_range must be two numbers separated by a comma, e.g. 1.0,10.0")
-    cf = cfg["circuit_folders"]
-    folders = cf if isinstance(cf, list) else [p.strip() for p in str(cf).split(",") if p.strip()]
-    cfg["circuit_folders"] = [os.path.expanduser(p) for p in folders]
-    pl = cfg["placers"]
-    cfg["placers"] = [str(p).strip() for p in pl] if isinstance(pl, list) else [p.strip() for p in str(pl).split(",") if p.strip()]
+    cfg["edge_weight_range"] = (float(span[0]), float(span[1]))
+    cfg["circuit_folders"] = [os.path.expanduser(name) for name in _as_name_list(cfg["circuit_folders"])]
+    cfg["placers"] = _as_name_list(cfg["placers"])
     return cfg
 
 
@@ -135,6 +145,7 @@ def reduce_table(local: np.ndarray, local_min: np.ndarray, device=None):
 
 
 def run_simulation(cfg, device=None, verbose=True):
+    from ._lib import QplaceError
     from .circuit import circuit_from_qasm
     from .placers import PLACERS
 
@@ -144,8 +155,17 @@ def run_simulation(cfg, device=None, verbose=True):
     repeats = int(cfg["repeats"])
     names = [p for p in cfg["placers"]]
     seed = cfg.get("seed")
+    if seed is None and world > 1:
+        # every rank must build the same machine: the edge weights come off the global random stream, so
+        # without a configured seed rank 0 draws one and all ranks use it
+        box = [random.randrange(1 << 62) if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        seed = box[0]
     if seed is not None:
         random.seed(int(seed))
+    if device is None and cfg.get("device") not in (None, ""):
+        import torch
+        device = torch.device(str(cfg["device"]))
     arch = build_arch(cfg)
     files = list_qasm(cfg["circuit_folders"])
     placers = {n: PLACERS[n](device) for n in names if n in PLACERS}
@@ -194,9 +214,11 @@ def run_simulation(cfg, device=None, verbose=True):
                     for dt, cost in zip(times, costs):
                         record(fi, pi, dt, cost)
                     continue
-                except Exception as exc:  # noqa: BLE001 - fall back to one repeat at a time
-                    if verbose:
-                        print(f"[{name}] batched run failed ({exc}); repeating one at a time")
+                except QplaceError:
+                    raise  # the library or the device failed: never paper over that with a slower path
+                except Exception as exc:  # noqa: BLE001 - what a repeat of the reference would raise (main.py:99-102):
+                    if verbose:           # run them one at a time so that each records its own inf
+                        print(f"[{name}] batched run raised ({type(exc).__name__}: {exc}); repeating one at a time")
             for rep in mine:
                 if world > 1 and name in ("RANDOM", "BFS"):
                     random.seed(zlib.crc32(f"{seed}|{path}|{name}|{rep}".encode()))

@@ -183,6 +183,11 @@ class Engine:
         self.device = device if device is not None else default_device()
         self._ws = None
 
+    def _on_device(self):
+        """The ABI acts on the current HIP device (grid sizing, occupancy queries, launches): make the
+        engine's device current for the duration of a call."""
+        return _torch().cuda.device(self.device)
+
     def _workspace(self, nbytes):
         torch = _torch()
         if self._ws is None or self._ws.numel() < nbytes:
@@ -206,8 +211,9 @@ class Engine:
             out = torch.empty(B, dtype=torch.float64, device=self.device)
         ws = self._workspace(lib().qp_slice_cost_workspace(dc.ir.T, B))
         tab = {"packed": dt.packed, "table": dt.table_only, "f64": dt.f64}[table]
-        check(lib().qp_slice_cost_v3(C.byref(dc.c), C.byref(tab), A.data_ptr(), B, Tp, ldq, out.data_ptr(),
-                                     ws.data_ptr(), ws.numel(), _stream_ptr(self.device)))
+        with self._on_device():
+            check(lib().qp_slice_cost_v3(C.byref(dc.c), C.byref(tab), A.data_ptr(), B, Tp, ldq, out.data_ptr(),
+                                         ws.data_ptr(), ws.numel(), _stream_ptr(self.device)))
         return out
 
     def cost_v3_static(self, dc: DeviceCircuit, dt: DistanceTable, A, out, table="packed"):
@@ -216,8 +222,9 @@ class Engine:
         than there is)."""
         B, Tp, ldq = self._check_partitions(dc, A)
         tab = {"packed": dt.packed, "table": dt.table_only, "f64": dt.f64}[table]
-        check(lib().qp_slice_cost_v3_static(C.byref(dc.c), C.byref(tab), A.data_ptr(), B, Tp, ldq, out.data_ptr(),
-                                            _stream_ptr(self.device)))
+        with self._on_device():
+            check(lib().qp_slice_cost_v3_static(C.byref(dc.c), C.byref(tab), A.data_ptr(), B, Tp, ldq, out.data_ptr(),
+                                                _stream_ptr(self.device)))
         return out
 
     def cost_v2(self, dc: DeviceCircuit, dt: DistanceTable, A, variant=QP_V2, out=None, table="packed"):
@@ -228,8 +235,9 @@ class Engine:
             out = torch.empty(B, dtype=torch.float64, device=self.device)
         ws = self._workspace(lib().qp_slice_cost_workspace(dc.ir.T, B))
         tab = dt.packed if table == "packed" else dt.f64
-        check(lib().qp_slice_cost_v2(C.byref(dc.c), C.byref(tab), A.data_ptr(), B, Tp, ldq, variant,
-                                     out.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(self.device)))
+        with self._on_device():
+            check(lib().qp_slice_cost_v2(C.byref(dc.c), C.byref(tab), A.data_ptr(), B, Tp, ldq, variant,
+                                         out.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(self.device)))
         return out
 
     def cost_matrix(self, kind, dc: DeviceCircuit, dt: DistanceTable, t, a, ops, n_ops, avail, n_avail, out=None):
@@ -238,9 +246,10 @@ class Engine:
         B, max_ops = ops.shape
         if out is None:
             out = torch.empty((B, max_ops, dt.C), dtype=torch.float64, device=self.device)
-        check(lib().qp_cost_matrix(kind, C.byref(dc.c), C.byref(dt.f64), B, t.data_ptr(), a.data_ptr(), a.shape[1],
-                                   ops.data_ptr(), n_ops.data_ptr(), max_ops, avail.data_ptr(), n_avail.data_ptr(),
-                                   out.data_ptr(), _stream_ptr(self.device)))
+        with self._on_device():
+            check(lib().qp_cost_matrix(kind, C.byref(dc.c), C.byref(dt.f64), B, t.data_ptr(), a.data_ptr(), a.shape[1],
+                                       ops.data_ptr(), n_ops.data_ptr(), max_ops, avail.data_ptr(), n_avail.data_ptr(),
+                                       out.data_ptr(), _stream_ptr(self.device)))
         return out
 
 
@@ -249,8 +258,9 @@ class Engine:
         torch = _torch()
         B, Tp, ldq = self._check_partitions(dc, A)
         out = torch.empty((B, n_cores), dtype=torch.int64, device=self.device)
-        check(lib().qp_core_activity(C.byref(dc.c), A.data_ptr(), B, Tp, ldq, int(n_cores), out.data_ptr(),
-                                     _stream_ptr(self.device)))
+        with self._on_device():
+            check(lib().qp_core_activity(C.byref(dc.c), A.data_ptr(), B, Tp, ldq, int(n_cores), out.data_ptr(),
+                                         _stream_ptr(self.device)))
         return out
 
     def comm_matrix(self, dc: DeviceCircuit, A, n_cores: int):
@@ -259,8 +269,9 @@ class Engine:
         B, Tp, ldq = self._check_partitions(dc, A)
         out = torch.empty((B, n_cores, n_cores), dtype=torch.int32, device=self.device)
         status = torch.empty(B, dtype=torch.int32, device=self.device)
-        check(lib().qp_comm_matrix(C.byref(dc.c), A.data_ptr(), B, Tp, ldq, int(n_cores), out.data_ptr(),
-                                   status.data_ptr(), _stream_ptr(self.device)))
+        with self._on_device():
+            check(lib().qp_comm_matrix(C.byref(dc.c), A.data_ptr(), B, Tp, ldq, int(n_cores), out.data_ptr(),
+                                       status.data_ptr(), _stream_ptr(self.device)))
         return out, status
 
     def gtrhqa_place(self, dc: DeviceCircuit, dt: DistanceTable, initial, cap: int, out=None):
@@ -275,8 +286,9 @@ class Engine:
         if out is None:
             out = torch.empty((B, dc.ir.T + 1, ldq), dtype=torch.uint8, device=self.device)
         ws = self._workspace(lib().qp_gtrhqa_workspace(dt.C))
-        check(lib().qp_gtrhqa_place(C.byref(dc.c), C.byref(dt.f64), initial.data_ptr(), B, ldq, int(cap),
-                                    out.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(self.device)))
+        with self._on_device():
+            check(lib().qp_gtrhqa_place(C.byref(dc.c), C.byref(dt.f64), initial.data_ptr(), B, ldq, int(cap),
+                                        out.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(self.device)))
         return out
 
 

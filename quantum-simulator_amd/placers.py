@@ -55,9 +55,9 @@ class _ArchTables:
 class _Context:
     """Everything a placer call needs for one (circuit, architecture) pair, cached on the placer."""
 
-    def __init__(self, circuit, arch, device):
+    def __init__(self, circuit, arch, device, ir=None):
         self.device = device
-        self.ir: CircuitIR = circuit_ir(circuit)
+        self.ir: CircuitIR = ir if ir is not None else circuit_ir(circuit)
         self.dc = E.DeviceCircuit(self.ir, device)
         self.arch = _ArchTables(arch.network, device)
         self.eng = E.get_engine(device)
@@ -130,10 +130,12 @@ class BasePlacer:
 
     # -- context ----------------------------------------------------------------------------------
     def _context(self, circuit, arch) -> _Context:
-        key = (id(circuit), sum(1 for _ in circuit), _ArchTables.fingerprint(arch.network))
+        # keyed on the circuit's IR object, which the context keeps alive (an id of a dead object could be reused)
+        ir = circuit_ir(circuit)
+        key = (id(ir), ir.n_gates if hasattr(ir, "n_gates") else len(ir.gate_q), _ArchTables.fingerprint(arch.network))
         if self._ctx_key != key:
             dev = self._device if self._device is not None else E.default_device()
-            self._ctx = _Context(circuit, arch, dev)
+            self._ctx = _Context(circuit, arch, dev, ir)
             self._ctx_key = key
             self.node_index = self._ctx.arch.index
             self._dist_matrix = self._ctx.arch.D

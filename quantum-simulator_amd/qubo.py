@@ -296,16 +296,18 @@ class DeviceQubo:
         """Exact energies (int32 [R]) of replica states Xt (int8 [R, Npad], R % 128 == 0)."""
         R = self._check_states(Xt)
         out = self._torch.empty(R, dtype=self._torch.int32, device=self.device)
-        self._lib.check(self._lib.lib().qp_qubo_energy_i32(self._C.byref(self.dense), Xt.data_ptr(), R,
-                                                           out.data_ptr(), self._stream()))
+        with self._torch.cuda.device(self.device):
+            self._lib.check(self._lib.lib().qp_qubo_energy_i32(self._C.byref(self.dense), Xt.data_ptr(), R,
+                                                               out.data_ptr(), self._stream()))
         return out
 
     def fields(self, Xt):
         """Local fields F[v, r] (int32 [Npad, R])."""
         R = self._check_states(Xt)
         out = self._torch.empty((self.model.Npad, R), dtype=self._torch.int32, device=self.device)
-        self._lib.check(self._lib.lib().qp_qubo_fields_i32(self._C.byref(self.dense), Xt.data_ptr(), R,
-                                                           out.data_ptr(), self._stream()))
+        with self._torch.cuda.device(self.device):
+            self._lib.check(self._lib.lib().qp_qubo_fields_i32(self._C.byref(self.dense), Xt.data_ptr(), R,
+                                                               out.data_ptr(), self._stream()))
         return out
 
     def anneal(self, R, sweeps, seed=42, beta=None, init=None):
@@ -319,6 +321,7 @@ class DeviceQubo:
         else:
             Xt = torch.zeros((R, self.model.Npad), dtype=torch.int8, device=self.device)
         dE = torch.empty(R, dtype=torch.int32, device=self.device)
-        self._lib.check(self._lib.lib().qp_qubo_anneal(self._C.byref(self.struct), R, sweeps, hot, cold, seed,
-                                                       Xt.data_ptr(), dE.data_ptr(), flags, self._stream()))
+        with self._torch.cuda.device(self.device):
+            self._lib.check(self._lib.lib().qp_qubo_anneal(self._C.byref(self.struct), R, sweeps, hot, cold, seed,
+                                                           Xt.data_ptr(), dE.data_ptr(), flags, self._stream()))
         return Xt, dE

@@ -188,7 +188,7 @@ class CircuitIR:
             gate_q = [tuple(r[:k]) for r, k in zip(rows, nq.tolist())]
             small = tab.shape[1] <= 2 or not (nq > 2).any()
             pair = (tab[:, 0].astype(np.int32), (tab[:, 1] if tab.shape[1] > 1 else np.full(len(tab), -1)).astype(np.int32))
-            return cls(len(qubits), gate_q, mr.tolist(), qubits=qubits, commands=circuit.get_commands,
+            return cls(len(qubits), gate_q, mr.tolist(), qubits=qubits, commands=weakref.WeakMethod(circuit.get_commands),
                        tables=pair if small and len(tab) else None, trusted=True)
         index = {q: i for i, q in enumerate(qubits)}
         commands = list(circuit)
@@ -315,8 +315,13 @@ class CircuitIR:
 
     @property
     def commands(self):
-        if callable(self._commands):
-            self._commands = self._commands()
+        made = self._commands
+        if isinstance(made, weakref.WeakMethod):  # held weakly so that the cached IR does not keep its circuit alive
+            made = made()
+            if made is None:
+                raise ValueError("the circuit this IR was built from no longer exists")
+        if callable(made):
+            self._commands = made()
         return self._commands
 
     def command_slices(self):

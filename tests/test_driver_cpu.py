@@ -187,3 +187,63 @@ def test_sharded_run_equals_single_rank(tmp_path):
         for x, y in zip(ra, rb):
             assert x == y or (math.isinf(x) and math.isinf(y))
     assert (tmp_path / "out.csv0").exists() and not (tmp_path / "out.csv1").exists()  # rank 0 writes the CSV
+
+
+UNSEEDED_WORKER = textwrap.dedent("""
+    import json, os, sys
+    sys.path.insert(0, {root!r})
+    import torch.distributed as dist
+    from quantum_simulator_amd import driver, placers
+
+    seen = []
+
+    class Fake:
+        def __init__(self, device=None):
+            pass
+        def place_per_timeslice(self, circuit, arch):
+            seen.append([d["weight"].hex() for _, _, d in arch.network.edges(data=True)])
+            return [dict()]
+        def per_timeslice_cost(self, circuit, part, arch):
+            return sum(d["weight"] for _, _, d in arch.network.edges(data=True))
+
+    placers.PLACERS.clear()
+    placers.PLACERS.update({{"HQA": Fake}})
+    dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=2)
+    cfg = driver.parse_config_file({cfg!r})
+    assert "seed" not in cfg
+    cfg["out_csv"] = {out!r} + os.environ["RANK"]
+    res = driver.run_simulation(cfg, device="cpu", verbose=False)
+    print("RESULT " + json.dumps([seen[0], res[0]["HQA_cost_mean"], res[0]["HQA_cost_min"]]))
+    dist.destroy_process_group()
+""")
+
+
+def test_two_ranks_without_a_seed_build_the_same_machine(tmp_path):
+    """No ``seed`` in the config: rank 0 draws one and every rank builds its edge weights from it, so the
+    reduced table describes one machine (mean == min when every repeat costs the same)."""
+    import json
+    from quantum_simulator_amd import circuit_to_qasm_str, layered_circuit
+    folder = tmp_path / "circ"
+    folder.mkdir()
+    (folder / "c.qasm").write_text(circuit_to_qasm_str(layered_circuit(6, 4, 0.5, seed=1)))
+    cfg = tmp_path / "cfg.txt"
+    cfg.write_text(EXAMPLE.replace("circuits/gen", str(folder)).replace("RANDOM, BFS, TRHQA, HQA, GTRHQA", "HQA")
+                   .replace("repeats = 3", "repeats = 4").replace("results_plot.png", "")
+                   .replace("num_cores_x = 2", "num_cores_x = 3").replace("num_cores_y = 1", "num_cores_y = 3"))
+    script = tmp_path / "w.py"
+    script.write_text(UNSEEDED_WORKER.format(root=ROOT, cfg=str(cfg), out=str(tmp_path / "out.csv")))
+    procs = []
+    for r in range(2):
+        # different hash seeds and start times: the ranks' own random streams differ
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29573",
+                   PYTHONHASHSEED=str(r + 1))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        out, _ = p.communicate(timeout=240)
+        assert p.returncode == 0, out
+        outs.append(json.loads([l for l in out.splitlines() if l.startswith("RESULT ")][0][7:]))
+    assert outs[0][0] == outs[1][0], "edge weights differ between ranks"
+    assert len(set(outs[0][0])) > 1
+    assert outs[0][1:] == outs[1][1:] and outs[0][1] == outs[0][2]
