@@ -280,6 +280,27 @@ int qp_cost_matrix(int32_t kind, const QpCircuit* circ, const QpDTable* dt, int6
                    int32_t max_ops, const uint8_t* avail, const int32_t* n_avail, double* cost_out,
                    void* stream);
 
+/* ---------------------------------------------------------------- HQA / TRHQA placement batches */
+
+/* B independent HQA (kind QP_CM_HQA) or TRHQA (QP_CM_TRHQA) placements of one circuit: the whole control loop
+ * of hqa_placer.place_per_timeslice (HQA_placer.py:56-176: per slice the gates whose qubits sit on different
+ * cores, the while-loop with its iteration budget, make-space when no core has room (:180-204), the op x core
+ * cost matrix (:112-122 with :208-241; TRHQA_placer.py:135-166 with :471-532), linear_sum_assignment (:126) and
+ * the moves (:129-145)).  Cost matrices are computed on the device (the kernel of qp_cost_matrix); the
+ * assignment solves stay on the host.  The batch is split over `lanes` host threads, each driving its instances
+ * through all slices on its own stream: streams[l] is the HIP stream of lane l (lanes of them, all on the current
+ * device, none of them busy with work this call must wait for).
+ * circ / dt: device tables as for qp_cost_matrix (dt QP_DT_F64).  slice_edge_ptr [T+1], edges [nE], D [C*C]:
+ * host copies of the circuit's gate list and of the distance matrix.  initial: host uint8 [B][Q], core index per
+ * qubit at slice 0.  rows_out: host uint8 [B][T][Q], row t = assignment after slice t (row 0 = initial).
+ * pinned: page-locked host memory the device can address (hipHostMalloc or equivalent), 16-byte aligned,
+ * qp_hqa_place_pinned_bytes(ldq, C, most gates in a slice, B, lanes) bytes with ldq = Q rounded up to 16: the
+ * kernel reads its inputs from it and writes the matrices into it, nothing is copied. */
+size_t qp_hqa_place_pinned_bytes(int32_t ldq, int32_t C, int32_t max_slice_edges, int64_t B, int32_t lanes);
+int qp_hqa_place_batch(int32_t kind, const QpCircuit* circ, const QpDTable* dt, const int32_t* slice_edge_ptr,
+                       const QpEdge* edges, const double* D, int32_t cap, const uint8_t* initial, int64_t B,
+                       uint8_t* rows_out, void* pinned, size_t pinned_bytes, int32_t lanes, void* const* streams);
+
 /* ---------------------------------------------------------------- device: GTRHQA placement */
 
 /* B independent GTRHQA placements of one circuit, every timeslice on the device (one workgroup walks

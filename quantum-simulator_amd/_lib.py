@@ -96,6 +96,10 @@ EXPORTS = {
     "qp_cost_matrix": (C.c_int, [C.c_int32, C.POINTER(QpCircuit), C.POINTER(QpDTable), C.c_int64, C.c_void_p,
                                  C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p]),
+    "qp_hqa_place_pinned_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32]),
+    "qp_hqa_place_batch": (C.c_int, [C.c_int32, C.POINTER(QpCircuit), C.POINTER(QpDTable), C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t,
+                                     C.c_int32, C.c_void_p]),
     "qp_gtrhqa_workspace": (C.c_size_t, [C.c_int32]),
     "qp_gtrhqa_place": (C.c_int, [C.POINTER(QpCircuit), C.POINTER(QpDTable), C.c_void_p, C.c_int64, C.c_int32,
                                   C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

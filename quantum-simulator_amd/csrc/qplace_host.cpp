@@ -262,6 +262,15 @@ int lsap_solve(int32_t nr, int32_t nc, const double* cost, int32_t ld, int32_t* 
 
 }  // namespace
 
+struct qp::LsapWork {
+    LsapScratch s;
+};
+qp::LsapWork* qp::lsap_work_new() { return new qp::LsapWork(); }
+void qp::lsap_work_free(qp::LsapWork* w) { delete w; }
+int qp::lsap(int32_t nr, int32_t nc, const double* cost, int32_t ld, int32_t* row_out, int32_t* col_out, qp::LsapWork* work) {
+    return lsap_solve(nr, nc, cost, ld, row_out, col_out, work->s);
+}
+
 extern "C" int qp_lsap_f64(int32_t nr, int32_t nc, const double* cost, int32_t* row_out, int32_t* col_out) {
     if (nr < 0 || nc < 0 || ((nr > 0 && nc > 0) && (!cost || !row_out || !col_out)))
         return qp::fail(QP_EINVAL, "qp_lsap_f64: bad argument");
@@ -332,35 +341,37 @@ extern "C" int qp_make_space(uint8_t* a, int64_t* occ, const int64_t* rows, int6
                              int32_t C, int32_t cap, const double* D) {
     if (!a || !occ || (n_rows > 0 && !rows) || !D || n_rows < 0 || Q <= 0 || lda < Q || C <= 0 || C > 256)
         return qp::fail(QP_EINVAL, "qp_make_space: bad arguments");
-    const int64_t lim = (int64_t)cap - 2;
     for (int64_t k = 0; k < n_rows; ++k) {
         if (rows[k] < 0) return qp::fail(QP_EINVAL, "qp_make_space: negative row index");
-        uint8_t* ar = a + (size_t)rows[k] * lda;
-        int64_t* oc = occ + (size_t)rows[k] * C;
-        for (int32_t core = 0; core < C; ++core) {
-            if (oc[core] <= lim) continue;
-            // the core's first two qubits as the row stands now (earlier cores may have sent it some)
-            int32_t inside[2], n_in = 0;
-            for (int32_t q = 0; q < Q && n_in < 2; ++q)
-                if (ar[q] == core) inside[n_in++] = q;
-            const double* drow = D + (size_t)core * C;
-            for (int32_t j = 0; j < n_in; ++j) {
-                int32_t best = -1;
-                for (int32_t tc = 0; tc < C; ++tc) {
-                    if (tc == core || oc[tc] >= (int64_t)cap - 1) continue;
-                    // strict comparisons keep the first of equal keys, as the reference's stable sort does
-                    if (best < 0 || drow[tc] < drow[best] || (drow[tc] == drow[best] && oc[tc] < oc[best])) best = tc;
-                }
-                if (best >= 0) {
-                    ar[inside[j]] = (uint8_t)best;
-                    --oc[core];
-                    ++oc[best];
-                }
-                if (oc[core] <= lim) break;
-            }
-        }
+        qp::make_space_row(a + (size_t)rows[k] * lda, occ + (size_t)rows[k] * C, Q, C, cap, D);
     }
     return QP_OK;
+}
+
+void qp::make_space_row(uint8_t* ar, int64_t* oc, int32_t Q, int32_t C, int32_t cap, const double* D) {
+    const int64_t lim = (int64_t)cap - 2;
+    for (int32_t core = 0; core < C; ++core) {
+        if (oc[core] <= lim) continue;
+        // the core's first two qubits as the row stands now (earlier cores may have sent it some)
+        int32_t inside[2], n_in = 0;
+        for (int32_t q = 0; q < Q && n_in < 2; ++q)
+            if (ar[q] == core) inside[n_in++] = q;
+        const double* drow = D + (size_t)core * C;
+        for (int32_t j = 0; j < n_in; ++j) {
+            int32_t best = -1;
+            for (int32_t tc = 0; tc < C; ++tc) {
+                if (tc == core || oc[tc] >= (int64_t)cap - 1) continue;
+                // strict comparisons keep the first of equal keys, as the reference's stable sort does
+                if (best < 0 || drow[tc] < drow[best] || (drow[tc] == drow[best] && oc[tc] < oc[best])) best = tc;
+            }
+            if (best >= 0) {
+                ar[inside[j]] = (uint8_t)best;
+                --oc[core];
+                ++oc[best];
+            }
+            if (oc[core] <= lim) break;
+        }
+    }
 }
 
 extern "C" int qp_dtable_symmetric(const double* D, int32_t C, double rel_tol) {
