@@ -145,24 +145,55 @@ def bench_cost_matrix(torch, dev, dc, ir, D, B, steps):
                          "note": "8 bytes written per entry; inputs are re-read from cache"}}
 
 
-def bench_shipped(dev):
+def bench_shipped(dev, rank=0, world=1):
     """The reference's shipped circuits (gate tables from tests/golden; the QASM files themselves do not travel):
     batches of whole placements + their costs, as the driver runs a config's repeats.  cfg2 = qft_n18 on the 4x4
-    mesh, cfg3 = qft_n63 on the 8x8 torus (one GPU's share of 64 repeats is 8; 64 are run)."""
+    mesh (256 repeats), cfg3 = qft_n63 on the 8x8 torus (64 repeats).  With more than one rank the repeats are
+    dealt round-robin to the ranks, as the driver deals them, and the per-placer sums and minima go through the
+    driver's final reduction (one SUM and one MIN all-reduce of a few doubles): every rank ends with the job's
+    mean and min cost."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from quantum_simulator_amd import driver
     from quantum_simulator_amd.golden import case_arch, case_circuit, load_case
     from quantum_simulator_amd.placers import PLACERS
     rows = []
+    names = ("HQA", "TRHQA", "GTRHQA", "BFS", "RANDOM")
     for cfg, name, B in (("cfg2", "qft18_mesh4x4_u", 256), ("cfg3", "qft63_torus8x8_u", 64)):
         gc = load_case(name)
         circ, arch = case_circuit(gc), case_arch(gc)
-        for pname in ("HQA", "TRHQA", "GTRHQA", "BFS", "RANDOM"):
+        mine = len([r for r in range(B) if r % world == rank])
+        sums = np.zeros((1, len(names), 4))
+        mins = np.full((1, len(names)), np.inf)
+        walls = []
+        for pi, pname in enumerate(names):
             placer = PLACERS[pname](dev)
+            random.seed(1000 + rank)  # RANDOM / BFS draw from the global stream: every rank its own
             placer.run_repeats(circ, arch, 2)
+            if world > 1:
+                dist.barrier()
             t0 = time.perf_counter()
-            _, costs = placer.run_repeats(circ, arch, B)
-            wall = time.perf_counter() - t0
-            rows.append({"config": cfg, "case": name, "placer": pname, "repeats": B, "slices": gc.T,
-                         "seconds": wall, "slice_steps_per_s": B * gc.T / wall, "mean_cost": float(sum(costs) / len(costs))})
+            costs = placer.run_repeats(circ, arch, mine)[1] if mine else []
+            torch.cuda.synchronize(dev)
+            walls.append(time.perf_counter() - t0)
+            fin = [c for c in costs if math.isfinite(c)]
+            sums[0, pi] = [sum(fin), len(fin), walls[-1], 1]
+            if fin:
+                mins[0, pi] = min(fin)
+        t0 = time.perf_counter()
+        sums, mins = driver.reduce_table(sums, mins, dev if world > 1 and dist.get_backend() == "nccl" else None)
+        reduce_ms = (time.perf_counter() - t0) * 1e3
+        wall = torch.tensor(walls, dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(wall, op=dist.ReduceOp.MAX)
+        for pi, pname in enumerate(names):
+            w = float(wall[pi].item())
+            rows.append({"config": cfg, "case": name, "placer": pname, "repeats": B, "ranks": world, "slices": gc.T,
+                         "seconds": w, "slice_steps_per_s": B * gc.T / w,
+                         "mean_cost": float(sums[0, pi, 0] / sums[0, pi, 1]) if sums[0, pi, 1] else math.inf,
+                         "min_cost": float(mins[0, pi]), "finite_repeats": int(sums[0, pi, 1]),
+                         "reduce_ms": reduce_ms if world > 1 else None})
     return rows
 
 
@@ -171,9 +202,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--weights", choices=["uniform", "integer"], default="integer",
-                    help="edge weights of the headline number: integer (2,2) -> exact uint16 table in LDS; "
-                         "uniform(1,3) -> fp64 table; the other one is run too and reported under other_variants")
+    ap.add_argument("--weights", choices=["uniform", "integer"], default="uniform",
+                    help="edge weights of the headline number: uniform(1,3) -> fp64 distance table, what the reference's "
+                         "own configs draw (multicore.py:159-161); integer (2,2) -> exact uint16 table, on this mesh the "
+                         "closed-form grid metric (a special case).  The other one is run too: other_variants")
     ap.add_argument("--single", action="store_true", help="run only the --weights variant")
     ap.add_argument("--partitions", type=int, default=4096, help="partitions per GPU")
     ap.add_argument("--qubits", type=int, default=1024)
@@ -184,7 +216,7 @@ def main():
     ap.add_argument("--pmove", type=float, default=0.95)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-qubo", action="store_true")
-    ap.add_argument("--qubo-sweeps", type=int, default=40)
+    ap.add_argument("--qubo-sweeps", type=int, default=1000)
     ap.add_argument("--qubo-replicas", type=int, default=4096)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -229,11 +261,14 @@ def main():
     out = torch.empty(B, dtype=torch.float64, device=dev)
     alg_bytes = B * ir.T * Q + 4 * ir.nE + 4 * (ir.T + 1) + 8 * B + 8 * C * C
 
+    archs = {}
+
     def distances(weights):
         random.seed(weight_seed)
         wr = (1.0, 3.0) if weights == "uniform" else (2.0, 2.0)
         arch = multicore(CX, CY, ncm_qubits=4, ncp_qubits=cap, edge_weight_range=wr, network_type="mesh")
         nodes, eu, ev, w = graph_tables(arch.network)
+        archs[weights] = arch
         return wr, apsp(len(nodes), eu, ev, w)
 
     place = None
@@ -315,7 +350,11 @@ def main():
         stats = torch.stack([out.sum(), torch.tensor(float(B), dtype=torch.float64, device=dev)])
         mn = out.min().reshape(1)
         reduce_ms = None
+        per_rank = [wall / args.steps * 1e3]
         if world > 1:
+            walls = [torch.zeros_like(tmax) for _ in range(world)]
+            dist.all_gather(walls, tmax)
+            per_rank = [float(w.item()) / args.steps * 1e3 for w in walls]
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             torch.cuda.synchronize(dev)
             r0 = time.perf_counter()
@@ -326,7 +365,7 @@ def main():
         wall = float(tmax.item())
         achieved = alg_bytes / (dev_ms * 1e-3) / 1e9
         return {"weights": f"{weights} {wr}", "value": world * B * ir.T * args.steps / wall, "unit": "evals/s",
-                "ms_per_step": wall / args.steps * 1e3,
+                "ms_per_step": wall / args.steps * 1e3, "ms_per_step_per_rank": per_rank,
                 "dtype": "u8 core ids / u32 sums" if dt.kind == QP_DT_U16 else "f64",
                 "table": how, "_closed": closed,
                 "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -338,9 +377,13 @@ def main():
     primary = run_variant(args.weights)
     others = []
     if not args.single:
-        if primary["_closed"]:
-            others.append(run_variant(args.weights, table="table"))
-        others.append(run_variant("uniform" if args.weights == "integer" else "integer"))
+        for weights in (("integer",) if args.weights == "uniform" else ("uniform",)):
+            v = run_variant(weights)
+            others.append(v)
+        for v in [primary] + list(others):
+            if v["_closed"]:  # the same integer table with the closed form switched off
+                others.append(run_variant("integer", table="table"))
+                break
 
     cm = None
     if not args.no_qubo:
@@ -359,10 +402,12 @@ def main():
             dist.all_reduce(fl, op=dist.ReduceOp.SUM)
             qubo["spin_flip_attempts_per_s"] = float(fl.item())
     shipped = None
-    if world == 1 and not args.no_qubo:
+    if not args.no_qubo:
         try:
-            shipped = bench_shipped(dev)
+            shipped = bench_shipped(dev, rank, world)
         except Exception as exc:  # noqa: BLE001 - a side table must not cost the headline line
+            if world > 1:
+                raise  # the other ranks are waiting in a collective
             shipped = {"error": f"{type(exc).__name__}: {exc}"}
     if rank == 0:
         D, kind, gpu_costs = primary.pop("_D"), primary.pop("_kind"), primary.pop("_costs")
@@ -382,16 +427,29 @@ def main():
             "shipped_circuits": shipped,
         }
         # HBM bytes per launch as measured with rocprofv3 PMC counters in a separate run of this workload
-        # (profiles/r01_traffic.json; FETCH_SIZE doubled as gfx950 requires for 16-byte-per-lane streams)
+        # (profiles/r02_traffic.json, one entry per kernel name; FETCH_SIZE doubled as gfx950 requires for
+        # 16-byte-per-lane streams).  An entry is used only for the kernel and the workload it was measured on.
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-                tr = json.load(f)
-            wk = tr["workload"]
-            if (wk["Q"], wk["T"], wk["B"], wk["weights"], wk.get("closed_form", False)) == \
-                    (Q, ir.T, B, args.weights, primary["_closed"]):
-                res["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            pass
+            with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as f:
+                measured = json.load(f)
+        except (OSError, ValueError):
+            measured = {}
+        for v in [primary] + others:
+            tr = measured.get(v["roofline"]["kernel"])
+            if tr and (tr.get("Q"), tr.get("T"), tr.get("B"), tr.get("source")) == (Q, ir.T, B, args.source):
+                v["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+                v["roofline"]["traffic_source"] = tr.get("profile")
+        by_w = {}
+        for v in [primary] + others:
+            key = ("uniform_fp64_table" if v["dtype"] == "f64" else
+                   "integer_closed_form" if v["_closed"] else "integer_uint16_table")
+            by_w[key] = {"frac": v["roofline"]["frac"], "kernel": v["roofline"]["kernel"], "kernel_ms": v["roofline"]["kernel_ms"],
+                         "evals_per_s": v["value"], "traffic": v["roofline"]["traffic"]}
+        res["roofline_by_weights"] = by_w
+        res["ms_per_step_per_rank"] = primary["ms_per_step_per_rank"]
+        ref1 = os.environ.get("QP_BENCH_REF_1GPU")
+        if ref1:  # evals/s of a one-GPU run of the same command, given by whoever runs the sweep
+            res["scaling_efficiency"] = primary["value"] / (world * float(ref1))
         primary.pop("_closed")
         for o in others:
             for k in ("_D", "_kind", "_costs", "_closed"):
@@ -444,7 +502,43 @@ def main():
                 if abs(float(gpu_costs[n_py]) - want) > tol * abs(want):
                     raise SystemExit(f"parity failure (python port) on sample partition {n_py}")
                 n_py += 1
-            res["cpu_baseline"] = {"value": n_all * ir.T / t_all, "unit": "evals/s", "cores": cores, "kind": "port",
+            # the reference's own structure: no distance matrix, a fresh weighted shortest-path search per term
+            # (Placer.py:63-76), on the first slices of one partition; and NumPy gathers on a precomputed matrix
+            from oracle import cpu_variants
+            ref_rate = ref_note = None
+            try:
+                arch0 = archs[args.weights]
+                node_list = list(arch0.network.nodes)
+                rows0 = sample[0].tolist()
+                n_sl, t_ref = 3, 0.0
+                while True:
+                    c0 = time.perf_counter()
+                    got_ref, searches = cpu_variants.cost_v3_reference_structure(arch0.network, node_list, ir.slices,
+                                                                                 ir.gate_q, ir.gate_mr, rows0, n_sl)
+                    t_ref = time.perf_counter() - c0
+                    if t_ref > 1.5 or n_sl >= ir.T:
+                        break
+                    n_sl = min(ir.T, n_sl * 2)
+                want_ref = O.cost_v3(ir.slices[:n_sl], ir.gate_q, ir.gate_mr, rows0[:n_sl], Dl)
+                if got_ref != want_ref:
+                    raise SystemExit(f"parity failure (search per term): {got_ref!r} vs {want_ref!r}")
+                ref_rate = n_sl / t_ref
+                ref_note = f"{searches} shortest-path searches for the first {n_sl} slices of one partition, {t_ref:.1f} s, one core"
+            except ImportError:
+                pass
+            npc = cpu_variants.NumpyCost(ir.slices, ir.gate_q, ir.gate_mr, D)
+            n_np, t_np = 0, 0.0
+            while t_np < 2.0:
+                k = n_np % len(sample)
+                c0 = time.perf_counter()
+                want = npc.cost(sample[k])
+                t_np += time.perf_counter() - c0
+                if abs(float(gpu_costs[k]) - want) > max(tol, 1e-12) * abs(want):
+                    raise SystemExit(f"parity failure (numpy) on sample partition {k}")
+                n_np += 1
+            res["cpu_baseline"] = {"reference_structure_evals_per_s": ref_rate, "reference_structure_sample": ref_note,
+                                   "numpy_evals_per_s": n_np * ir.T / t_np,
+                                   "value": n_all * ir.T / t_all, "unit": "evals/s", "cores": cores, "kind": "port",
                                    "sample": f"{n_all} evaluations over {len(sample)} of this run's partitions x {ir.T} "
                                              f"slices through oracle/cost_oracle.c (gcc -O2, precomputed distance "
                                              f"matrix, sequential sums) on {cores} threads, {t_all:.1f} s; every result "

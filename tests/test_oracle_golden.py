@@ -268,3 +268,23 @@ def test_core_activity_restatement_matches_reference_fixture():
         for pname, want in gold[name].items():
             got = O.core_activity(gc.slices, gc.gate_q, gc.gate_mr, gc.part(pname).tolist(), gc.C)
             assert got == want, (name, pname)
+
+
+@pytest.mark.parametrize("name", ["qft18_mesh4x4_u", "shor5_star4_u", "bigadder_torus3x3_u"])
+def test_cpu_baseline_variants_match_reference_costs(name):
+    """The two extra CPU forms bench.py times (a fresh shortest-path search per term, as the reference does;
+    NumPy gathers on a precomputed matrix) against the reference's own costs in the fixtures."""
+    from conftest import case_arch, load_case
+    from oracle import cpu_variants
+    gc = load_case(name)
+    arch = case_arch(gc)
+    nodes = list(arch.network.nodes)
+    for p in ("HQA", "TRHQA"):
+        if not gc.has(p):
+            continue
+        rows = gc.part(p).tolist()
+        got, searches = cpu_variants.cost_v3_reference_structure(arch.network, nodes, gc.slices, gc.gate_q, gc.gate_mr,
+                                                                 rows, gc.T)
+        assert got == gc.cost(p) and searches > 0
+        vec = cpu_variants.NumpyCost(gc.slices, gc.gate_q, gc.gate_mr, gc.D).cost(gc.part(p))
+        assert abs(vec - gc.cost(p)) <= 1e-12 * abs(gc.cost(p))
