@@ -197,6 +197,58 @@ def bench_shipped(dev, rank=0, world=1):
     return rows
 
 
+def bench_broken_links(torch, dev, S=1024):
+    """simulate_broken_links as one batch (HQA_placer.py:325-361): S damaged copies of the 8x8 torus (every link
+    broken with probability 0.1), qft_n63 placed on each by HQA, every placement costed with its own table.
+    Reports the three phases: distance matrices (host threads), placements (native lanes + device cost
+    matrices), and the cost launch with one table per partition."""
+    import numpy as np
+    from quantum_simulator_amd import engine
+    from quantum_simulator_amd.golden import case_arch, case_circuit, load_case
+    from quantum_simulator_amd.placers import PLACERS
+    gc = load_case("qft63_torus8x8_u")
+    circ, arch = case_circuit(gc), case_arch(gc)
+    placer = PLACERS["HQA"](dev)
+    ctx = placer._context(circ, arch)
+    rng = np.random.default_rng(99)
+    W = np.tile(np.asarray(ctx.arch.w, np.float64), (S, 1))
+    W[rng.random(W.shape) < 0.1] = np.inf
+    threads = max(1, min(16, len(os.sched_getaffinity(0))))
+    t0 = time.perf_counter()
+    tables = engine.apsp_batch(ctx.arch.C, ctx.arch.eu, ctx.arch.ev, W, threads=threads)
+    t_apsp = time.perf_counter() - t0
+    tab = np.arange(S, dtype=np.int32)
+    placer.place_batch(circ, arch, B=8, tables=tables[:8], tab_index=tab[:8])
+    t0 = time.perf_counter()
+    rows = placer.place_batch(circ, arch, B=S, tables=tables, tab_index=tab)
+    t_place = time.perf_counter() - t0
+    pad = np.zeros(rows.shape[:2] + (ctx.dc.ldq,), np.uint8)
+    pad[:, :, :ctx.ir.Q] = rows
+    Dz = tables.copy()
+    Dz[:, np.arange(ctx.arch.C), np.arange(ctx.arch.C)] = 0.0
+    d_tab, d_idx, d_A = torch.from_numpy(Dz).to(dev), torch.from_numpy(tab).to(dev), torch.from_numpy(pad).to(dev)
+    out = torch.empty(S, dtype=torch.float64, device=dev)
+    ctx.eng.cost_v3_multi(ctx.dc, d_tab, d_idx, d_A, out=out)
+    torch.cuda.synchronize(dev)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 20
+    ev0.record(torch.cuda.current_stream(dev))
+    for _ in range(reps):
+        ctx.eng.cost_v3_multi(ctx.dc, d_tab, d_idx, d_A, out=out)
+    ev1.record(torch.cuda.current_stream(dev))
+    torch.cuda.synchronize(dev)
+    ms = ev0.elapsed_time(ev1) / reps
+    costs = out.cpu().numpy()
+    bytes_ = S * (gc.T * ctx.dc.ldq + 8 * ctx.arch.C ** 2) + 8 * ctx.ir.nE
+    return {"workload": f"{S} damaged copies of the 8x8 torus (links broken with p = 0.1), qft_n63 ({gc.T} slices) placed by "
+                        f"HQA on each, one distance table per partition",
+            "apsp_s": t_apsp, "apsp_threads": threads, "networks_per_s": S / t_apsp,
+            "place_s": t_place, "place_slice_steps_per_s": S * gc.T / t_place,
+            "cost_ms": ms, "cost_evals_per_s": S * gc.T / (ms * 1e-3),
+            "cost_gbs": bytes_ / (ms * 1e-3) / 1e9, "finite_costs": int(np.isfinite(costs).sum()),
+            "note": "cost launch: one workgroup per partition stages that partition's 32 KB table in LDS; bytes = rows + tables"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -409,6 +461,12 @@ def main():
             if world > 1:
                 raise  # the other ranks are waiting in a collective
             shipped = {"error": f"{type(exc).__name__}: {exc}"}
+    broken = None
+    if world == 1 and not args.no_qubo:
+        try:
+            broken = bench_broken_links(torch, dev)
+        except Exception as exc:  # noqa: BLE001 - a side table must not cost the headline line
+            broken = {"error": f"{type(exc).__name__}: {exc}"}
     if rank == 0:
         D, kind, gpu_costs = primary.pop("_D"), primary.pop("_kind"), primary.pop("_costs")
         res = {
@@ -424,7 +482,7 @@ def main():
                        "table": primary["table"]},
             "roofline": primary["roofline"], "mean_cost": primary["mean_cost"], "min_cost": primary["min_cost"],
             "reduce_ms": primary["reduce_ms"], "gtrhqa_place": place, "cost_matrix": cm, "qubo": qubo,
-            "shipped_circuits": shipped,
+            "shipped_circuits": shipped, "broken_links": broken,
         }
         # HBM bytes per launch as measured with rocprofv3 PMC counters in a separate run of this workload
         # (profiles/r02_traffic.json, one entry per kernel name; FETCH_SIZE doubled as gfx950 requires for

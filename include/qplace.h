@@ -119,6 +119,14 @@ const char* qp_last_error(void);
 int qp_apsp_f64(int32_t C, int32_t n_edges, const int32_t* eu, const int32_t* ev, const double* w,
                 double* D_out /* host [C*C] */);
 
+/* The same for S networks that share their links (eu, ev) and differ in the weights: w [S][n_edges],
+ * D_out [S][C*C], on `threads` host threads.  This is the distance work of simulate_broken_links
+ * (HQA_placer.py:325-361 and its copies), which re-places the circuit on many copies of the network with some
+ * link weights set to infinity: an infinite weight keeps the link traversable at infinite cost, as networkx
+ * treats it. */
+int qp_apsp_f64_batch(int32_t C, int32_t n_edges, const int32_t* eu, const int32_t* ev, const double* w, int32_t S,
+                      double* D_out /* host [S][C*C] */, int32_t threads);
+
 /* Unweighted hop counts as doubles (+inf when unreachable), host.  Replaces the
  * nx.shortest_path_length calls without weight (Qubo_placer.py:35-38,192,201). */
 int qp_hops_f64(int32_t C, int32_t n_edges, const int32_t* eu, const int32_t* ev,
@@ -233,6 +241,14 @@ size_t qp_slice_cost_workspace(int32_t T, int64_t B);
 int qp_slice_cost_v3(const QpCircuit* circ, const QpDTable* dt, const uint8_t* A, int64_t B, int32_t Tp,
                      int32_t ldq, double* out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* qp_slice_cost_v3 with one distance table per partition: tables is dev double [S][C*C] (row = source core,
+ * zero diagonal, entries may be +inf), partition b is costed with table tab_index[b] (dev int32 [B], values
+ * 0..S-1).  This is the cost step of simulate_broken_links (HQA_placer.py:325-361 and its copies in
+ * TRHQA_placer.py:628-669, BFS_placer.py:241-278, Random_placer.py:255-296) for all damaged networks in one launch.
+ * Needs no workspace; sums are formed in a fixed order. */
+int qp_slice_cost_v3_multi(const QpCircuit* circ, const double* tables, int32_t S, int32_t C, const int32_t* tab_index,
+                           const uint8_t* A, int64_t B, int32_t Tp, int32_t ldq, double* out, void* stream);
+
 /* qp_slice_cost_v3 for callers that cannot allocate device memory or hand over a workspace: code under HIP
  * graph capture, tight serving loops, harnesses that forbid hipMalloc.  No counterpart in the reference.
  * Same arguments, same kernels and bit-for-bit the same results as qp_slice_cost_v3; the partial sums (and
@@ -280,6 +296,14 @@ int qp_cost_matrix(int32_t kind, const QpCircuit* circ, const QpDTable* dt, int6
                    int32_t max_ops, const uint8_t* avail, const int32_t* n_avail, double* cost_out,
                    void* stream);
 
+/* qp_cost_matrix with one distance table per instance: tables is dev double [S][C*C] (row = source core, zero
+ * diagonal), instance b reads table tab_index[b] (dev or device-visible host int32 [B]).  For placements on many
+ * damaged copies of one network at once (simulate_broken_links, HQA_placer.py:325-361, TRHQA_placer.py:628-669). */
+int qp_cost_matrix_multi(int32_t kind, const QpCircuit* circ, const double* tables, int32_t S, int32_t C,
+                         const int32_t* tab_index, int64_t B, const uint8_t* a, int32_t ldq, const int32_t* ops,
+                         const int32_t* n_ops, int32_t max_ops, const uint8_t* avail, const int32_t* n_avail,
+                         double* cost_out, void* stream);
+
 /* ---------------------------------------------------------------- HQA / TRHQA placement batches */
 
 /* B independent HQA (kind QP_CM_HQA) or TRHQA (QP_CM_TRHQA) placements of one circuit: the whole control loop
@@ -300,6 +324,14 @@ size_t qp_hqa_place_pinned_bytes(int32_t ldq, int32_t C, int32_t max_slice_edges
 int qp_hqa_place_batch(int32_t kind, const QpCircuit* circ, const QpDTable* dt, const int32_t* slice_edge_ptr,
                        const QpEdge* edges, const double* D, int32_t cap, const uint8_t* initial, int64_t B,
                        uint8_t* rows_out, void* pinned, size_t pinned_bytes, int32_t lanes, void* const* streams);
+
+/* The same with one distance table per instance (placements on many damaged copies of one network,
+ * simulate_broken_links, HQA_placer.py:325-361 / TRHQA_placer.py:628-669): tables dev double [S][C*C], D host
+ * double [S][C*C] (the same matrices), tab_index host int32 [B] (null: every instance uses table 0). */
+int qp_hqa_place_batch_multi(int32_t kind, const QpCircuit* circ, const double* tables, int32_t S, int32_t C,
+                             const int32_t* tab_index, const int32_t* slice_edge_ptr, const QpEdge* edges, const double* D,
+                             int32_t cap, const uint8_t* initial, int64_t B, uint8_t* rows_out, void* pinned,
+                             size_t pinned_bytes, int32_t lanes, void* const* streams);
 
 /* ---------------------------------------------------------------- device: GTRHQA placement */
 

@@ -100,6 +100,16 @@ EXPORTS = {
     "qp_hqa_place_batch": (C.c_int, [C.c_int32, C.POINTER(QpCircuit), C.POINTER(QpDTable), C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t,
                                      C.c_int32, C.c_void_p]),
+    "qp_hqa_place_batch_multi": (C.c_int, [C.c_int32, C.POINTER(QpCircuit), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,
+                                           C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
+    "qp_cost_matrix_multi": (C.c_int, [C.c_int32, C.POINTER(QpCircuit), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                       C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]),
+    "qp_slice_cost_v3_multi": (C.c_int, [C.POINTER(QpCircuit), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                         C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "qp_apsp_f64_batch": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                    C.c_int32]),
     "qp_gtrhqa_workspace": (C.c_size_t, [C.c_int32]),
     "qp_gtrhqa_place": (C.c_int, [C.POINTER(QpCircuit), C.POINTER(QpDTable), C.c_void_p, C.c_int64, C.c_int32,
                                   C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -140,6 +140,33 @@ extern "C" int qp_apsp_f64(int32_t C, int32_t nE, const int32_t* eu, const int32
     return QP_OK;
 }
 
+extern "C" int qp_apsp_f64_batch(int32_t C, int32_t nE, const int32_t* eu, const int32_t* ev, const double* w,
+                                 int32_t S, double* D, int32_t threads) {
+    if (S < 0 || C <= 0 || nE < 0 || (S > 0 && !D) || (S > 0 && nE > 0 && (!eu || !ev || !w)))
+        return qp::fail(QP_EINVAL, "qp_apsp_f64_batch: bad argument");
+    for (int32_t e = 0; e < nE; ++e)
+        if (eu[e] < 0 || eu[e] >= C || ev[e] < 0 || ev[e] >= C)
+            return qp::fail(QP_EINVAL, "qp_apsp_f64_batch: edge %d endpoint out of range", e);
+    threads = std::max(1, std::min(threads, S));
+    std::vector<int> rcs(threads, QP_OK);
+    auto work = [&](int32_t tid) {
+        for (int32_t k = tid; k < S; k += threads) {
+            const int rc = qp_apsp_f64(C, nE, eu, ev, w + (size_t)k * nE, D + (size_t)k * C * C);
+            if (rc != QP_OK) rcs[tid] = rc;
+        }
+    };
+    if (threads == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (int32_t tdx = 0; tdx < threads; ++tdx) pool.emplace_back(work, tdx);
+        for (auto& th : pool) th.join();
+    }
+    for (int rc : rcs)
+        if (rc != QP_OK) return qp::fail(rc, "qp_apsp_f64_batch: a graph of the batch was rejected");
+    return QP_OK;
+}
+
 extern "C" int qp_hops_f64(int32_t C, int32_t nE, const int32_t* eu, const int32_t* ev, double* H) {
     if (C <= 0 || nE < 0 || !H || (nE > 0 && (!eu || !ev))) return qp::fail(QP_EINVAL, "qp_hops_f64: bad argument");
     Adj a;

@@ -23,18 +23,20 @@ namespace {
 
 inline size_t up16(size_t x) { return (x + 15) & ~(size_t)15; }
 
-// Bytes of one instance's share of a lane's pinned slab: live row, op list, core list, the two counts, matrix.
+// Bytes of one instance's share of a lane's pinned slab: live row, op list, core list, the two counts, the table
+// index, the matrix.
 size_t instance_bytes(int32_t ldq, int32_t C, int32_t max_ops) {
-    return up16((size_t)ldq) + up16((size_t)max_ops * 4) + up16((size_t)C) + 16 + up16((size_t)max_ops * C * 8);
+    return up16((size_t)ldq) + up16((size_t)max_ops * 4) + up16((size_t)C) + 16 + up16((size_t)max_ops * C * 8);  // 16: two counts and the table index
 }
 
 struct Batch {
-    int32_t kind, T, Q, ldq, C, cap, max_ops;
+    int32_t kind, T, Q, ldq, C, cap, max_ops, S;
     const QpCircuit* circ;
-    const QpDTable* dt;
+    const double* tables;  // dev [S][C*C]
+    const int32_t* tab;    // host [B] table of every instance, or null: all use table 0
     const int32_t* sep;
     const QpEdge* edges;
-    const double* D;
+    const double* D;       // host [S][C*C]
     const uint8_t* initial;
     uint8_t* out;
     int32_t rows_out;
@@ -70,13 +72,19 @@ void run_lane(const Batch& bx, Lane& ln) {
     p += up16((size_t)nb * 4);
     int32_t* pnav = reinterpret_cast<int32_t*>(p);
     p += up16((size_t)nb * 4);
+    int32_t* ptab = reinterpret_cast<int32_t*>(p);
+    p += up16((size_t)nb * 4);
     double* pcost = reinterpret_cast<double*>(p);
 
     std::vector<uint8_t> a((size_t)nb * Q);
     std::vector<int64_t> occ((size_t)nb * C);
     std::vector<uint8_t> rem((size_t)nb * bx.max_ops);
     std::vector<int32_t> nrem(nb), budget(nb), spent(nb), go, rr(std::max(bx.max_ops, C)), cc(std::max(bx.max_ops, C));
-    qp::LsapWork* work = qp::lsap_work_new();
+    struct WorkHolder {  // freed on every way out of the lane
+        qp::LsapWork* w = qp::lsap_work_new();
+        ~WorkHolder() { qp::lsap_work_free(w); }
+    } holder;
+    qp::LsapWork* work = holder.w;
     memset(pa, 0, (size_t)nb * ldq);  // pad bytes of the live rows stay zero
 
     for (int64_t k = 0; k < nb; ++k) {
@@ -117,7 +125,8 @@ void run_lane(const Batch& bx, Lane& ln) {
                 bool room = false;
                 for (int32_t c = 0; c < C && !room; ++c) room = ok[c] <= cap - 2;
                 if (room) go.push_back((int32_t)k);
-                else qp::make_space_row(a.data() + (size_t)k * Q, occ.data() + (size_t)k * C, Q, C, cap, bx.D);
+                else qp::make_space_row(a.data() + (size_t)k * Q, occ.data() + (size_t)k * C, Q, C, cap,
+                                        bx.D + (size_t)(bx.tab ? bx.tab[ln.b0 + k] : 0) * C * C);
             }
             if (go.empty()) continue;
             const int32_t ng = (int32_t)go.size();
@@ -137,10 +146,11 @@ void run_lane(const Batch& bx, Lane& ln) {
                 for (int32_t c = 0; c < C; ++c)
                     if (ok[c] <= cap - 2) ag[m++] = (uint8_t)c;
                 pnav[g] = m;
+                ptab[g] = bx.tab ? bx.tab[ln.b0 + k] : 0;
             }
-            const int rc = qp_cost_matrix(bx.kind, bx.circ, bx.dt, ng, nullptr, pa, ldq, pops, pnops, E, pavail, pnav, pcost,
-                                          ln.stream);
-            if (rc != QP_OK) return lane_fail(ln, rc, "qp_cost_matrix", qp_last_error());
+            const int rc = qp_cost_matrix_multi(bx.kind, bx.circ, bx.tables, bx.S, C, ptab, ng, pa, ldq, pops, pnops, E, pavail,
+                                                pnav, pcost, ln.stream);
+            if (rc != QP_OK) return lane_fail(ln, rc, "qp_cost_matrix_multi", qp_last_error());
             // wait for the matrices: poll the stream (an interrupt-driven wait costs more than the kernel)
             hipError_t st;
             unsigned spins = 0;
@@ -180,7 +190,6 @@ void run_lane(const Batch& bx, Lane& ln) {
         for (int64_t k = 0; k < nb; ++k)
             memcpy(bx.out + ((size_t)(ln.b0 + k) * bx.rows_out + t) * Q, a.data() + (size_t)k * Q, Q);
     }
-    qp::lsap_work_free(work);
 }
 
 }  // namespace
@@ -191,25 +200,31 @@ extern "C" size_t qp_hqa_place_pinned_bytes(int32_t ldq, int32_t C, int32_t max_
     return (size_t)B * instance_bytes(ldq, C, std::max(max_slice_edges, 1)) + (size_t)lanes * 128;
 }
 
-extern "C" int qp_hqa_place_batch(int32_t kind, const QpCircuit* circ, const QpDTable* dt, const int32_t* slice_edge_ptr,
-                                  const QpEdge* edges, const double* D, int32_t cap, const uint8_t* initial, int64_t B,
-                                  uint8_t* rows_out, void* pinned, size_t pinned_bytes, int32_t lanes,
-                                  void* const* streams) {
-    if (kind != QP_CM_HQA && kind != QP_CM_TRHQA) return qp::fail(QP_EINVAL, "qp_hqa_place_batch: kind must be QP_CM_HQA or QP_CM_TRHQA");
-    if (!circ || !dt || !slice_edge_ptr || !D || !initial || !rows_out || !pinned || !streams)
-        return qp::fail(QP_EINVAL, "qp_hqa_place_batch: null argument");
-    if (B <= 0 || lanes <= 0 || cap < 0) return qp::fail(QP_EINVAL, "qp_hqa_place_batch: B and lanes must be positive");
-    if (circ->Q <= 0 || circ->T < 0 || (circ->nE > 0 && !edges)) return qp::fail(QP_EINVAL, "qp_hqa_place_batch: bad circuit");
-    if (dt->kind != QP_DT_F64 || dt->C <= 0 || dt->C > 256) return qp::fail(QP_EINVAL, "qp_hqa_place_batch: needs a QP_DT_F64 table of at most 256 cores");
+extern "C" int qp_hqa_place_batch_multi(int32_t kind, const QpCircuit* circ, const double* tables, int32_t S, int32_t C,
+                                        const int32_t* tab_index, const int32_t* slice_edge_ptr, const QpEdge* edges,
+                                        const double* D, int32_t cap, const uint8_t* initial, int64_t B, uint8_t* rows_out,
+                                        void* pinned, size_t pinned_bytes, int32_t lanes, void* const* streams) {
+    const char* fn = "qp_hqa_place_batch";
+    if (kind != QP_CM_HQA && kind != QP_CM_TRHQA) return qp::fail(QP_EINVAL, "%s: kind must be QP_CM_HQA or QP_CM_TRHQA", fn);
+    if (!circ || !tables || !slice_edge_ptr || !D || !initial || !rows_out || !pinned || !streams)
+        return qp::fail(QP_EINVAL, "%s: null argument", fn);
+    if (B <= 0 || lanes <= 0 || cap < 0 || S <= 0) return qp::fail(QP_EINVAL, "%s: B, S and lanes must be positive", fn);
+    if (circ->Q <= 0 || circ->T < 0 || (circ->nE > 0 && !edges)) return qp::fail(QP_EINVAL, "%s: bad circuit", fn);
+    if (C <= 0 || C > 256) return qp::fail(QP_EINVAL, "%s: 1..256 cores", fn);
+    if (tab_index)
+        for (int64_t b = 0; b < B; ++b)
+            if (tab_index[b] < 0 || tab_index[b] >= S) return qp::fail(QP_EINVAL, "%s: table index of instance %lld out of range", fn, (long long)b);
     Batch bx{};
     bx.kind = kind;
     bx.T = circ->T;
     bx.Q = circ->Q;
     bx.ldq = (circ->Q + 15) / 16 * 16;
-    bx.C = dt->C;
+    bx.C = C;
+    bx.S = S;
     bx.cap = cap;
     bx.circ = circ;
-    bx.dt = dt;
+    bx.tables = tables;
+    bx.tab = tab_index;
     bx.sep = slice_edge_ptr;
     bx.edges = edges;
     bx.D = D;
@@ -221,13 +236,13 @@ extern "C" int qp_hqa_place_batch(int32_t kind, const QpCircuit* circ, const QpD
     bx.max_ops = most;
     for (int64_t b = 0; b < B; ++b)
         for (int32_t q = 0; q < bx.Q; ++q)
-            if (initial[(size_t)b * bx.Q + q] >= bx.C) return qp::fail(QP_EINVAL, "qp_hqa_place_batch: initial holds a core index outside the table");
+            if (initial[(size_t)b * bx.Q + q] >= bx.C) return qp::fail(QP_EINVAL, "%s: initial holds a core index outside the table", fn);
     HIP_TRY(hipGetDevice(&bx.device));
     lanes = (int32_t)std::min<int64_t>(lanes, B);
     const size_t per = instance_bytes(bx.ldq, bx.C, bx.max_ops);
     if (pinned_bytes < (size_t)B * per + (size_t)lanes * 128)
-        return qp::fail(QP_ENOSPC, "qp_hqa_place_batch: pinned buffer needs %zu bytes", (size_t)B * per + (size_t)lanes * 128);
-    if (reinterpret_cast<uintptr_t>(pinned) % 16 != 0) return qp::fail(QP_EINVAL, "qp_hqa_place_batch: pinned buffer must be 16-byte aligned");
+        return qp::fail(QP_ENOSPC, "%s: pinned buffer needs %zu bytes", fn, (size_t)B * per + (size_t)lanes * 128);
+    if (reinterpret_cast<uintptr_t>(pinned) % 16 != 0) return qp::fail(QP_EINVAL, "%s: pinned buffer must be 16-byte aligned", fn);
     if (bx.T == 0) {
         memcpy(rows_out, initial, (size_t)B * bx.Q);
         return QP_OK;
@@ -251,4 +266,14 @@ extern "C" int qp_hqa_place_batch(int32_t kind, const QpCircuit* circ, const QpD
     for (int32_t l = 0; l < lanes; ++l)
         if (ln[l].rc != QP_OK) return qp::fail(ln[l].rc, "%s", ln[l].msg);
     return QP_OK;
+}
+
+extern "C" int qp_hqa_place_batch(int32_t kind, const QpCircuit* circ, const QpDTable* dt, const int32_t* slice_edge_ptr,
+                                  const QpEdge* edges, const double* D, int32_t cap, const uint8_t* initial, int64_t B,
+                                  uint8_t* rows_out, void* pinned, size_t pinned_bytes, int32_t lanes,
+                                  void* const* streams) {
+    if (!dt) return qp::fail(QP_EINVAL, "qp_hqa_place_batch: null argument");
+    if (dt->kind != QP_DT_F64 || !dt->table) return qp::fail(QP_EINVAL, "qp_hqa_place_batch: needs a QP_DT_F64 table");
+    return qp_hqa_place_batch_multi(kind, circ, static_cast<const double*>(dt->table), 1, dt->C, nullptr, slice_edge_ptr, edges,
+                                    D, cap, initial, B, rows_out, pinned, pinned_bytes, lanes, streams);
 }

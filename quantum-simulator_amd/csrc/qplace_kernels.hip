@@ -1231,6 +1231,7 @@ struct CmArgs {
     const int32_t* n_avail;
     double* out;
     int32_t C, ldq, max_ops, kind;
+    const int32_t* tab;  // optional: instance b uses the table D + tab[b] * C * C
 };
 
 __device__ inline double pymax(double a, double b) { return b > a ? b : a; }  // Python's max(a, b)
@@ -1304,7 +1305,7 @@ __global__ __launch_bounds__(256) void k_cost_matrix(CmArgs p) {
     __syncthreads();
     for (int j = threadIdx.x; j < n_av; j += blockDim.x) {
         const int32_t c = min((int32_t)p.avail[(size_t)b * C + j], C - 1);
-        const double* Dc = p.D + c;  // column c of the table
+        const double* Dc = p.D + (p.tab ? (size_t)p.tab[b] * C * C : (size_t)0) + c;  // column c of the instance's table
         double* outp = p.out + ((size_t)b * p.max_ops + i0) * C + j;
         // four ops at a time: their eight distance loads are issued before any of the arithmetic
         const int nloc = i1 - i0;
@@ -1737,31 +1738,31 @@ extern "C" int qp_slice_cost_v2(const QpCircuit* circ, const QpDTable* dt, const
     return QP_OK;
 }
 
-extern "C" int qp_cost_matrix(int32_t kind, const QpCircuit* circ, const QpDTable* dt, int64_t B, const int32_t* t,
-                              const uint8_t* a, int32_t ldq, const int32_t* ops, const int32_t* n_ops, int32_t max_ops,
-                              const uint8_t* avail, const int32_t* n_avail, double* cost_out, void* stream_) {
-    if (kind != QP_CM_HQA && kind != QP_CM_TRHQA && kind != QP_CM_GTRHQA) return qp::fail(QP_EINVAL, "qp_cost_matrix: bad kind");
-    if (!circ || !dt || !a || !ops || !n_ops || !avail || !n_avail || !cost_out)
-        return qp::fail(QP_EINVAL, "qp_cost_matrix: null argument");
-    if (B <= 0 || B > 65535) return qp::fail(QP_EINVAL, "qp_cost_matrix: B must be 1..65535 per call");
-    if (max_ops <= 0) return qp::fail(QP_EINVAL, "qp_cost_matrix: max_ops must be positive");
-    if (dt->kind != QP_DT_F64 || !dt->table) return qp::fail(QP_EINVAL, "qp_cost_matrix: needs a QP_DT_F64 distance table");
-    if (dt->C <= 0 || dt->C > 256) return qp::fail(QP_EINVAL, "qp_cost_matrix: bad core count");
-    if (!circ->edges || (kind != QP_CM_GTRHQA && !circ->lookahead)) return qp::fail(QP_EINVAL, "qp_cost_matrix: circuit tables missing");
-    if (ldq < circ->Q) return qp::fail(QP_EINVAL, "qp_cost_matrix: ldq < Q");
-    (void)t;
+namespace {
+
+int cost_matrix_impl(const char* fn, int32_t kind, const QpCircuit* circ, const double* D, int32_t C, const int32_t* tab,
+                     int64_t B, const uint8_t* a, int32_t ldq, const int32_t* ops, const int32_t* n_ops, int32_t max_ops,
+                     const uint8_t* avail, const int32_t* n_avail, double* cost_out, void* stream_) {
+    if (kind != QP_CM_HQA && kind != QP_CM_TRHQA && kind != QP_CM_GTRHQA) return qp::fail(QP_EINVAL, "%s: bad kind", fn);
+    if (!circ || !D || !a || !ops || !n_ops || !avail || !n_avail || !cost_out) return qp::fail(QP_EINVAL, "%s: null argument", fn);
+    if (B <= 0 || B > 65535) return qp::fail(QP_EINVAL, "%s: B must be 1..65535 per call", fn);
+    if (max_ops <= 0) return qp::fail(QP_EINVAL, "%s: max_ops must be positive", fn);
+    if (C <= 0 || C > 256) return qp::fail(QP_EINVAL, "%s: bad core count", fn);
+    if (!circ->edges || (kind != QP_CM_GTRHQA && !circ->lookahead)) return qp::fail(QP_EINVAL, "%s: circuit tables missing", fn);
+    if (ldq < circ->Q) return qp::fail(QP_EINVAL, "%s: ldq < Q", fn);
     CmArgs p{};
     p.edges = circ->edges;
     p.lookahead = circ->lookahead;
-    p.D = static_cast<const double*>(dt->table);
-    p.t = t;
+    p.D = D;
+    p.tab = tab;
+    p.t = nullptr;
     p.a = a;
     p.ops = ops;
     p.n_ops = n_ops;
     p.avail = avail;
     p.n_avail = n_avail;
     p.out = cost_out;
-    p.C = dt->C;
+    p.C = C;
     p.ldq = ldq;
     p.max_ops = max_ops;
     p.kind = kind;
@@ -1770,6 +1771,140 @@ extern "C" int qp_cost_matrix(int32_t kind, const QpCircuit* circ, const QpDTabl
     if (kind == QP_CM_HQA) k_cost_matrix<QP_CM_HQA><<<grid, 256, 0, stream>>>(p);
     else if (kind == QP_CM_TRHQA) k_cost_matrix<QP_CM_TRHQA><<<grid, 256, 0, stream>>>(p);
     else k_cost_matrix<QP_CM_GTRHQA><<<grid, 256, 0, stream>>>(p);
+    HIP_TRY(hipGetLastError());
+    return QP_OK;
+}
+
+}  // namespace
+
+extern "C" int qp_cost_matrix(int32_t kind, const QpCircuit* circ, const QpDTable* dt, int64_t B, const int32_t* t,
+                              const uint8_t* a, int32_t ldq, const int32_t* ops, const int32_t* n_ops, int32_t max_ops,
+                              const uint8_t* avail, const int32_t* n_avail, double* cost_out, void* stream) {
+    (void)t;
+    if (!dt) return qp::fail(QP_EINVAL, "qp_cost_matrix: null argument");
+    if (dt->kind != QP_DT_F64 || !dt->table) return qp::fail(QP_EINVAL, "qp_cost_matrix: needs a QP_DT_F64 distance table");
+    return cost_matrix_impl("qp_cost_matrix", kind, circ, static_cast<const double*>(dt->table), dt->C, nullptr, B, a, ldq, ops,
+                            n_ops, max_ops, avail, n_avail, cost_out, stream);
+}
+
+extern "C" int qp_cost_matrix_multi(int32_t kind, const QpCircuit* circ, const double* tables, int32_t S, int32_t C,
+                                    const int32_t* tab_index, int64_t B, const uint8_t* a, int32_t ldq, const int32_t* ops,
+                                    const int32_t* n_ops, int32_t max_ops, const uint8_t* avail, const int32_t* n_avail,
+                                    double* cost_out, void* stream) {
+    if (!tables || !tab_index || S <= 0) return qp::fail(QP_EINVAL, "qp_cost_matrix_multi: null argument");
+    return cost_matrix_impl("qp_cost_matrix_multi", kind, circ, tables, C, tab_index, B, a, ldq, ops, n_ops, max_ops, avail,
+                            n_avail, cost_out, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Cost V3 with one distance table per instance (many damaged copies of one network)
+// ------------------------------------------------------------------------------------------------
+
+namespace {
+
+struct V3MultiArgs {
+    const uint8_t* A;
+    const int32_t* sep;
+    const QpEdge* edges;
+    const double* tables;
+    const int32_t* tab;
+    double* out;
+    int64_t B;
+    int32_t T, Tp, ldq, Q, C, S;
+};
+
+constexpr int kMultiThreads = 256;
+
+// One workgroup per instance at a time: it stages the instance's table in LDS (TAB_LDS) or reads it where it
+// lies, its waves take every fourth row (moves into the row from the row before, then the row's gates), and
+// the instance's cost is the fixed-order sum of the lanes' and waves' partial sums.
+template <bool TAB_LDS>
+__global__ __launch_bounds__(kMultiThreads) void k_cost_v3_multi(V3MultiArgs p) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    __shared__ double red[kMultiThreads / kWave];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const uint32_t C = (uint32_t)p.C, last = C * C - 1u;
+    for (int64_t b = blockIdx.x; b < p.B; b += gridDim.x) {
+        const int32_t ti = min(max(p.tab[b], 0), p.S - 1);
+        const double* tab = p.tables + (size_t)ti * C * C;
+        if constexpr (TAB_LDS) {
+            __syncthreads();  // the previous instance's look-ups are done
+            double* dst = reinterpret_cast<double*>(smem);
+            for (uint32_t k = threadIdx.x; k <= last; k += kMultiThreads) dst[k] = tab[k];
+            __syncthreads();
+            tab = dst;
+        }
+        const uint8_t* base = p.A + (size_t)b * p.Tp * p.ldq;
+        double acc = 0.0;
+        for (int t = wave; t < p.T; t += kMultiThreads / kWave) {
+            const uint8_t* cur = base + (size_t)t * p.ldq;
+            if (t >= 2) {  // movement is charged from row 2 on
+                const uint8_t* prv = cur - p.ldq;
+                for (int q = lane; q < p.Q; q += kWave) {
+                    const uint32_t from = prv[q], to = cur[q];
+                    if (from != to) acc += tab[min(from * C + to, last)];
+                }
+            }
+            for (int e = p.sep[t] + lane; e < p.sep[t + 1]; e += kWave) {
+                const QpEdge ed = p.edges[e];
+                const uint32_t u = cur[ed.u], v = cur[ed.v];
+                if (u != v) acc += tab[min(u * C + v, last)];
+            }
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) red[wave] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double s = 0.0;
+            for (int w = 0; w < kMultiThreads / kWave; ++w) s += red[w];
+            p.out[b] = s;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int qp_slice_cost_v3_multi(const QpCircuit* circ, const double* tables, int32_t S, int32_t C,
+                                      const int32_t* tab_index, const uint8_t* A, int64_t B, int32_t Tp, int32_t ldq,
+                                      double* out, void* stream_) {
+    if (!circ || !tables || !tab_index || !A || !out) return qp::fail(QP_EINVAL, "qp_slice_cost_v3_multi: null argument");
+    if (B <= 0 || S <= 0) return qp::fail(QP_EINVAL, "qp_slice_cost_v3_multi: B and S must be positive");
+    if (C <= 0 || C > 256) return qp::fail(QP_EINVAL, "qp_slice_cost_v3_multi: 1..256 cores");
+    if (circ->Q <= 0 || circ->T < 0 || ldq < circ->Q) return qp::fail(QP_EINVAL, "qp_slice_cost_v3_multi: bad circuit sizes or ldq < Q");
+    if (Tp < circ->T) return qp::fail(QP_EINVAL, "qp_slice_cost_v3_multi: partition has %d rows, circuit has %d slices", Tp, circ->T);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (circ->T == 0) {
+        k_fill<<<(unsigned)((B + 255) / 256), 256, 0, stream>>>(out, B, 0.0);
+        HIP_TRY(hipGetLastError());
+        return QP_OK;
+    }
+    if (!circ->slice_edge_ptr || (circ->nE > 0 && !circ->edges)) return qp::fail(QP_EINVAL, "qp_slice_cost_v3_multi: circuit edge tables missing");
+    V3MultiArgs p{};
+    p.A = A;
+    p.sep = circ->slice_edge_ptr;
+    p.edges = circ->edges;
+    p.tables = tables;
+    p.tab = tab_index;
+    p.out = out;
+    p.B = B;
+    p.T = circ->T;
+    p.Tp = Tp;
+    p.ldq = ldq;
+    p.Q = circ->Q;
+    p.C = C;
+    p.S = S;
+    const size_t tab_bytes = (size_t)C * C * sizeof(double);
+    const int cus = qp::device_cus();
+    if (tab_bytes <= 128 * 1024) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cost_v3_multi<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tab_bytes));
+        int per_cu = 1;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k_cost_v3_multi<true>), kMultiThreads, tab_bytes));
+        const unsigned grid = (unsigned)std::min<int64_t>((int64_t)cus * std::max(per_cu, 1), B);
+        k_cost_v3_multi<true><<<grid, kMultiThreads, tab_bytes, stream>>>(p);
+    } else {
+        const unsigned grid = (unsigned)std::min<int64_t>((int64_t)cus * 8, B);
+        k_cost_v3_multi<false><<<grid, kMultiThreads, 0, stream>>>(p);
+    }
     HIP_TRY(hipGetLastError());
     return QP_OK;
 }

@@ -52,6 +52,17 @@ def apsp(C_: int, eu, ev, w) -> np.ndarray:
     return D
 
 
+def apsp_batch(C_: int, eu, ev, W, threads: int = 8) -> np.ndarray:
+    """Distance matrices [S, C, C] of S networks that share their links and differ in the weights W [S, E]."""
+    eu = np.ascontiguousarray(eu, np.int32)
+    ev = np.ascontiguousarray(ev, np.int32)
+    W = np.ascontiguousarray(W, np.float64)
+    S = W.shape[0]
+    D = np.empty((S, C_, C_), np.float64)
+    check(lib().qp_apsp_f64_batch(C_, len(eu), ptr(eu), ptr(ev), ptr(W), S, ptr(D), int(threads)))
+    return D
+
+
 def hops(C_: int, eu, ev) -> np.ndarray:
     eu = np.ascontiguousarray(eu, np.int32)
     ev = np.ascontiguousarray(ev, np.int32)
@@ -214,6 +225,23 @@ class Engine:
         with self._on_device():
             check(lib().qp_slice_cost_v3(C.byref(dc.c), C.byref(tab), A.data_ptr(), B, Tp, ldq, out.data_ptr(),
                                          ws.data_ptr(), ws.numel(), _stream_ptr(self.device)))
+        return out
+
+    def cost_v3_multi(self, dc: DeviceCircuit, tables, tab_index, A, out=None):
+        """HQA-family cost of B dense partitions, partition b with the distance table ``tables[tab_index[b]]``:
+        ``tables`` float64 [S, C, C] and ``tab_index`` int32 [B] on the device (zero diagonals, inf allowed)."""
+        torch = _torch()
+        B, Tp, ldq = self._check_partitions(dc, A)
+        if tables.dtype != torch.float64 or tables.dim() != 3 or tables.shape[1] != tables.shape[2] or not tables.is_contiguous():
+            raise ValueError("tables must be a contiguous float64 [S, C, C] tensor")
+        if tab_index.dtype != torch.int32 or tab_index.shape != (B,) or not tab_index.is_contiguous():
+            raise ValueError("tab_index must be a contiguous int32 [B] tensor")
+        if out is None:
+            out = torch.empty(B, dtype=torch.float64, device=self.device)
+        with self._on_device():
+            check(lib().qp_slice_cost_v3_multi(C.byref(dc.c), tables.data_ptr(), tables.shape[0], tables.shape[1],
+                                               tab_index.data_ptr(), A.data_ptr(), B, Tp, ldq, out.data_ptr(),
+                                               _stream_ptr(self.device)))
         return out
 
     def cost_v3_static(self, dc: DeviceCircuit, dt: DistanceTable, A, out, table="packed"):

@@ -364,13 +364,15 @@ class _HqaFamily(BasePlacer):
         return rows
 
     # -- many instances at once ----------------------------------------------------------------------
-    def place_batch(self, circuit, multicore_arch, initial=None, B=None, threads=None):
+    def place_batch(self, circuit, multicore_arch, initial=None, B=None, threads=None, tables=None, tab_index=None):
         """B independent placements of one circuit on one architecture through qp_hqa_place_batch: the whole
         per-slice loop is native; the batch is split over ``threads`` host threads (default: half the CPUs this
         process may use, at most 8), each driving its instances on its own stream (cost matrices on the
         device, assignment solves on the host).  ``initial`` is uint8 [B, Q] (row 0 of each instance; default:
         B copies of the block assignment, i.e. B identical repeats as main.py:88-92 runs them).  Returns uint8
-        [B, T, Q]; instance b equals what ``place_per_timeslice`` gives when started from ``initial[b]``."""
+        [B, T, Q]; instance b equals what ``place_per_timeslice`` gives when started from ``initial[b]``.
+        With ``tables`` (float64 [S, C, C] distance matrices on the host) and ``tab_index`` (int [B]) instance b
+        is placed on the network whose distances are ``tables[tab_index[b]]`` (damaged copies of the machine)."""
         import ctypes as C_
         import torch
         ctx = self._context(circuit, multicore_arch)
@@ -397,13 +399,64 @@ class _HqaFamily(BasePlacer):
         slab, streams = ctx.lane_resources(need, lanes)
         handles = (C_.c_void_p * lanes)(*[st.cuda_stream for st in streams])
         edges = np.ascontiguousarray(ir.edge_records)
-        Dh = np.ascontiguousarray(D, np.float64)
-        torch.cuda.synchronize(ctx.device)  # the circuit and distance tables were uploaded on another stream
+        if tables is None:
+            Dh = np.ascontiguousarray(D, np.float64)
+            f64 = ctx.arch.table.f64
+            torch.cuda.synchronize(ctx.device)  # the circuit and distance tables were uploaded on another stream
+            with torch.cuda.device(ctx.device):
+                check(lib().qp_hqa_place_batch(self._kind, C_.byref(ctx.dc.c), C_.byref(f64), ptr(sep),
+                                               edges.ctypes.data, ptr(Dh), int(cap), ptr(initial), B, ptr(out),
+                                               slab.data_ptr(), slab.numel(), lanes, handles))
+            return out
+        Dh = np.ascontiguousarray(tables, np.float64)
+        if Dh.ndim != 3 or Dh.shape[1:] != (C, C):
+            raise ValueError("tables must be [S, C, C]")
+        tab = np.ascontiguousarray(tab_index, np.int32)
+        if tab.shape != (B,):
+            raise ValueError("tab_index must have one entry per instance")
+        Dz = Dh.copy()
+        Dz[:, np.arange(C), np.arange(C)] = 0.0  # the device tables carry a zero diagonal
+        d_tab = torch.from_numpy(Dz).to(ctx.device)
+        torch.cuda.synchronize(ctx.device)
         with torch.cuda.device(ctx.device):
-            check(lib().qp_hqa_place_batch(self._kind, C_.byref(ctx.dc.c), C_.byref(ctx.arch.table.f64), ptr(sep),
-                                           edges.ctypes.data, ptr(Dh), int(cap), ptr(initial), B, ptr(out),
-                                           slab.data_ptr(), slab.numel(), lanes, handles))
+            check(lib().qp_hqa_place_batch_multi(self._kind, C_.byref(ctx.dc.c), d_tab.data_ptr(), Dh.shape[0], C, ptr(tab),
+                                                 ptr(sep), edges.ctypes.data, ptr(Dh), int(cap), ptr(initial), B, ptr(out),
+                                                 slab.data_ptr(), slab.numel(), lanes, handles))
         return out
+
+    def simulate_broken_links(self, circuit, multicore_arch, num_simulations=10, break_probability=0.1):
+        """HQA_placer.py:325-361 == TRHQA_placer.py:628-669, all simulations at once: the placement draws no
+        random numbers, so the links to break are drawn for every simulation first (the same draws in the same
+        order as the reference's loop makes them), then all damaged networks get their distance matrices in one
+        threaded batch, the circuit is placed on all of them as one placement batch with a table per instance,
+        and one launch costs every placement with its own table."""
+        import torch
+        intact = multicore_arch.network
+        links = list(intact.edges)
+        ctx = self._context(circuit, multicore_arch)
+        S = int(num_simulations)
+        if S <= 0:
+            return []
+        broken = [{link for link in links if random.random() < break_probability} for _ in range(S)]
+        arch = ctx.arch
+        pos = {}
+        for k, (u, v) in enumerate(zip(arch.eu, arch.ev)):
+            pos[(arch.nodes[u], arch.nodes[v])] = k
+            pos[(arch.nodes[v], arch.nodes[u])] = k
+        W = np.tile(np.asarray(arch.w, np.float64), (S, 1))
+        for s_, links_ in enumerate(broken):
+            for a, b in links_:
+                W[s_, pos[(a, b)]] = np.inf
+        tables = E.apsp_batch(arch.C, arch.eu, arch.ev, W)
+        rows = self.place_batch(circuit, multicore_arch, B=S, tables=tables, tab_index=np.arange(S, dtype=np.int32))
+        pad = np.zeros(rows.shape[:2] + (ctx.dc.ldq,), np.uint8)
+        pad[:, :, :ctx.ir.Q] = rows
+        Dz = tables.copy()
+        Dz[:, np.arange(arch.C), np.arange(arch.C)] = 0.0
+        costs = ctx.eng.cost_v3_multi(ctx.dc, torch.from_numpy(Dz).to(ctx.device),
+                                      torch.arange(S, dtype=torch.int32, device=ctx.device),
+                                      torch.from_numpy(pad).to(ctx.device)).cpu().numpy()
+        return [(links_, float(c)) for links_, c in zip(broken, costs)]
 
     @staticmethod
     def _rows_out(T):
@@ -466,6 +519,9 @@ class gtrhqa_placer(_HqaFamily):
     def __init__(self, device=None):
         super().__init__(device)
         self.name = "GTRHQA"
+
+    # one damaged network at a time (the device placer takes one distance table per launch)
+    simulate_broken_links = BasePlacer.simulate_broken_links
 
     def place_rows(self, ctx: _Context, cap: int):
         """GTRHQA_placer.py:62-265.  Returns T+1 rows: slice t starts from row t-1 (row 0 for t = 0)

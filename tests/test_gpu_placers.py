@@ -508,3 +508,77 @@ def test_driver_two_ranks_share_the_gpu(tmp_path):
     batched, single = outs[0]
     assert batched == single and len(batched) == 2
     assert all(np.isfinite(x) for row in batched for x in row)
+
+
+@pytest.mark.parametrize("Q,T,C,S", [(63, 70, 64, 9), (40, 30, 16, 5), (300, 12, 200, 4), (1024, 9, 256, 3)])
+def test_cost_v3_with_a_table_per_partition(Q, T, C, S):
+    """qp_slice_cost_v3_multi: every partition with its own distance table (damaged copies of one network, some
+    links infinite) against the single-table entry point and the oracle."""
+    import torch
+    from oracle import placer_oracle as O
+    from quantum_simulator_amd import engine, layered_gate_arrays
+    from quantum_simulator_amd.timeslices import CircuitIR
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(Q + S)
+    q0, q1, _ = layered_gate_arrays(Q, T, 0.5, seed=Q)
+    keep = rng.random(len(q0)) > 0.2
+    ir = CircuitIR.from_gate_tables(Q, q0[keep], q1[keep])
+    eu = list(range(C)) + [int(x) for x in rng.integers(0, C, size=C // 2)]
+    ev = [(i + 1) % C for i in range(C)] + [int(x) for x in rng.integers(0, C, size=C // 2)]
+    ok = [k for k in range(len(eu)) if eu[k] != ev[k]]
+    eu, ev = [eu[k] for k in ok], [ev[k] for k in ok]
+    W = np.tile(rng.uniform(1, 3, size=len(eu)), (S, 1))
+    for s in range(1, S):
+        W[s, rng.random(len(eu)) < 0.15] = np.inf
+    tables = engine.apsp_batch(C, eu, ev, W)
+    dc, eng = engine.DeviceCircuit(ir, dev), engine.Engine(dev)
+    B = 2 * S + 1
+    tab = (np.arange(B) % S).astype(np.int32)
+    A = rng.integers(0, C, size=(B, ir.T, dc.ldq), dtype=np.uint8)
+    A[0, 1:] = A[0, :1]
+    Ad = torch.from_numpy(A).to(dev)
+    got = eng.cost_v3_multi(dc, torch.from_numpy(tables).to(dev), torch.from_numpy(tab).to(dev), Ad).cpu().numpy()
+    assert got.tobytes() == eng.cost_v3_multi(dc, torch.from_numpy(tables).to(dev), torch.from_numpy(tab).to(dev), Ad).cpu().numpy().tobytes()
+    for b in range(B):
+        D = tables[tab[b]]
+        want = O.cost_v3(ir.slices, ir.gate_q, ir.gate_mr, A[b, :, :Q].tolist(), D.tolist())
+        if np.isinf(want):
+            assert np.isinf(got[b])
+        else:
+            assert abs(got[b] - want) <= 1e-12 * max(1.0, abs(want)), (b, got[b], want)
+        one = float(eng.cost_v3(dc, engine.DistanceTable(D, dev), Ad[b:b + 1], table="f64").cpu()[0])
+        assert (np.isinf(one) and np.isinf(got[b])) or abs(one - got[b]) <= 1e-12 * max(1.0, abs(one))
+
+
+@pytest.mark.parametrize("pname", ["HQA", "TRHQA"])
+def test_place_batch_with_a_table_per_instance(pname):
+    """A placement batch in which every instance has its own damaged network equals the placements made one
+    damaged network at a time."""
+    import random
+    from quantum_simulator_amd import engine
+    from quantum_simulator_amd.placers import PLACERS
+    gc = load_case("qft18_mesh4x4_u")
+    circ, arch = case_circuit(gc), case_arch(gc)
+    placer = PLACERS[pname]()
+    ctx = placer._context(circ, arch)
+    rng = np.random.default_rng(3)
+    S = 6
+    W = np.tile(np.asarray(ctx.arch.w, np.float64), (S, 1))
+    for s in range(1, S):
+        W[s, rng.random(W.shape[1]) < 0.12] = np.inf
+    tables = engine.apsp_batch(ctx.arch.C, ctx.arch.eu, ctx.arch.ev, W)
+    got = placer.place_batch(circ, arch, B=S, tables=tables, tab_index=np.arange(S, dtype=np.int32))
+    assert (got[0] == gc.part(pname)).all()  # table 0 is the intact network
+    intact = arch.network
+    links = list(intact.edges)
+    try:
+        for s in range(1, S):
+            damaged = intact.copy()
+            for k, (a, b) in enumerate(links):
+                damaged[a][b]["weight"] = float(W[s, k])
+            arch.network = damaged
+            one = PLACERS[pname]()
+            rows = one.place_rows(one._context(circ, arch), arch.qpu_qubit_num)
+            assert (got[s] == np.array(rows)).all(), (pname, s)
+    finally:
+        arch.network = intact

@@ -388,3 +388,20 @@ def test_make_space_native_equals_python():
                                Q, lda, C, cap, _lib.ptr(D)) == 0
         assert (got_a == want_a).all() and (got_occ == want_occ).all(), trial
     assert L.qp_make_space(None, None, None, 0, 1, 1, 1, 2, None) < 0
+
+
+def test_apsp_batch_equals_one_at_a_time():
+    """qp_apsp_f64_batch (threaded) == qp_apsp_f64 per network, bit for bit, including links of infinite weight."""
+    from quantum_simulator_amd import engine
+    rng = np.random.default_rng(5)
+    C = 12
+    eu = list(range(C)) + [0, 3, 7]
+    ev = [(i + 1) % C for i in range(C)] + [6, 9, 11]
+    W = rng.uniform(1, 3, size=(9, len(eu)))
+    W[1, 2] = W[1, 5] = np.inf
+    W[4, :] = np.inf
+    W[6] = np.floor(W[6])
+    got = engine.apsp_batch(C, eu, ev, W, threads=4)
+    for s in range(W.shape[0]):
+        assert got[s].tobytes() == engine.apsp(C, eu, ev, W[s]).tobytes()
+    assert np.isinf(got[4][0, 1]) and got[4][2, 2] == 0
