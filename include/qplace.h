@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define QP_VERSION 100
+#define QP_VERSION 200
 
 #define QP_OK 0
 #define QP_EINVAL (-1)   /* bad argument (shape, alignment, range) */
@@ -370,29 +370,31 @@ int qp_comm_matrix(const QpCircuit* circ, const uint8_t* A, int64_t B, int32_t T
 /* The QUBO placer's objective (Qubo_placer.py:84-133) over binary variables x[t,j,i] (active qubit i
  * of slice t on core j) and slack bits y[t,j,p], written as
  *     E(s) = constant + sum_v linear[v] s_v + sum_{v<w} S[v][w] s_v s_w,
- * all integers.  Variable order inside slice t: v = off[t] + j*(n_t+cap) + k, k < n_t for x, else y;
- * every slice is padded to a multiple of 128 variables (padding variables are always 0).
- * S is block-tridiagonal over slices and is passed as int8 "segments": for the rows of slice t, each
- * segment is a dense row-major matrix [rows of slice t][K columns] multiplying the K variables that
- * start at xoff; segments of one slice are summed (a coupling larger than 127 is split into layers). */
-typedef struct QpQuboSeg {
-    const int8_t* mat; /* dev */
-    int32_t ld;        /* row pitch in bytes */
-    int32_t K;         /* columns, multiple of 128 */
-    int64_t xoff;      /* first variable (padded axis) the columns refer to */
-} QpQuboSeg;
-
-typedef struct QpQuboDense {
-    int32_t T;
-    int32_t Npad;              /* padded variable count, multiple of 128 */
+ * all integers.  State vector: slice t occupies [off[t], off[t+1]); inside it v = off[t] + j*pitch[t] + k, k < n[t]
+ * for x, n[t] <= k < n[t]+cap for y, the rest of the pitch (n[t]+cap rounded up to 32) and of the slice (rounded
+ * up to 128) is padding that must be zero.  S is never stored.  Inside a slice it is the Kronecker sum
+ * I_C (x) same[t] + (J-I)_C (x) diag(8 on the x rows): same[t] holds the couplings between the variables of one
+ * core (x-x +8, -20 more for interacting qubits, x-y -8, y-y +8; the same for every core) and is the only dense
+ * piece, an int8 matrix contracted with the states by MFMA, core by core.  Between slices t and t+1 it is
+ * hops10 (x) matching(next[t]): 10 * hops[j][l] between x[t,j,i] and x[t+1,l,next[t][i]]. */
+typedef struct QpQuboKron {
+    int32_t T, C, cap, nmax;   /* slices, cores (<= 32), capacity (<= 32), max_t n[t] */
+    int64_t Npad;              /* length of a state vector, multiple of 128 */
     int32_t constant;
-    int32_t pad_;
-    const QpQuboSeg* segs;     /* dev */
-    const int32_t* seg_ptr;    /* dev [T+1]: segments of slice t are segs[seg_ptr[t] .. seg_ptr[t+1]) */
-    const int32_t* tile_slice; /* dev [Npad/128]: slice of each 128-variable tile */
-    const int64_t* off;        /* dev [T+1]: padded variable offset of each slice */
+    int32_t n_tiles;           /* sum_t C * (rows of same[t] / 128) */
+    const int32_t* n;          /* dev [T] active qubits per slice */
+    const int32_t* pitch;      /* dev [T] state bytes per core, multiple of 32 */
+    const int64_t* off;        /* dev [T+1] */
+    const int8_t* same;        /* dev: same[t] at same + same_off[t], row-major, rows = columns = pitch[t] rounded
+                                  up to 128, zero outside the (n[t]+cap)^2 block; 16-byte aligned */
+    const int64_t* same_off;   /* dev [T+1] */
+    const int32_t* tile_slice; /* dev [n_tiles]: slice of every (core, 128-row tile of same[t]) work item */
+    const int32_t* tile_first; /* dev [T+1]: first work item of every slice */
     const int32_t* linear;     /* dev [Npad] */
-} QpQuboDense;
+    const int32_t* next;       /* dev [T][nmax]: index in slice t+1 of the same qubit, -1 = not active there */
+    const int32_t* prev;       /* dev [T][nmax]: the same towards slice t-1 */
+    const int32_t* hops10;     /* dev [C*C]: 10 * hop count */
+} QpQuboKron;
 
 /* Structure of the same model for the annealer (all pointers dev; per-(slice, qubit) tables have row
  * pitch nmax = max_t n_t). */
@@ -409,17 +411,23 @@ typedef struct QpQuboStruct {
     const int32_t* nbr_ptr; /* [T*nmax+1] CSR over interaction partners (used when the degree is > 1) */
     const int16_t* nbr;
     const uint8_t* hops;    /* [C*C] hop counts */
+    const int32_t* pitch;   /* [T] state bytes per core (QpQuboKron.pitch) */
 } QpQuboStruct;
 
-/* Local fields F[v][r] = sum_w S[v][w] s_w of R replica states (int8 0/1, stored replica-major:
- * Xt[r][v], r < R, v < Npad; R a multiple of 128) by int8 MFMA.  F: dev int32 [Npad][R].
- * The energy change of flipping v in replica r is (1 - 2 s_v)(linear[v] + F[v][r]). */
-int qp_qubo_fields_i32(const QpQuboDense* model, const int8_t* Xt, int32_t R, int32_t* F, void* stream);
+/* Device workspace (bytes) of the two calls below for R replicas: one core mask per (slice, qubit, replica). */
+size_t qp_qubo_workspace(const QpQuboKron* model, int32_t R);
 
-/* Exact energies energy[r] = E(state r) of R replica states, same contraction with the reduction
+/* Local fields F[v][r] = sum_w S[v][w] s_w of R replica states (int8 0/1, stored replica-major:
+ * Xt[r][v], r < R, v < Npad; R a multiple of 128; 16-byte aligned).  F: dev int32 [Npad][R] (zero on padding).
+ * The energy change of flipping v in replica r is (1 - 2 s_v)(linear[v] + F[v][r]). */
+int qp_qubo_fields_i32(const QpQuboKron* model, const int8_t* Xt, int32_t R, int32_t* F, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
+/* Exact energies energy[r] = E(state r) of R replica states: the same contraction with the reduction
  * sum_v s_v (2 linear[v] + F[v][r]) fused into its epilogue (integer atomics: order-independent).
  * This is the number pyqubo's decoded sample reports as .energy (Qubo_placer.py:141-142). */
-int qp_qubo_energy_i32(const QpQuboDense* model, const int8_t* Xt, int32_t R, int32_t* energy, void* stream);
+int qp_qubo_energy_i32(const QpQuboKron* model, const int8_t* Xt, int32_t R, int32_t* energy, void* workspace,
+                       size_t workspace_bytes, void* stream);
 
 /* Replica-parallel simulated annealing (stands in for neal.SimulatedAnnealingSampler().sample,
  * Qubo_placer.py:139-140; R plays num_reads).  Metropolis sweeps over all variables with a geometric

@@ -36,20 +36,18 @@ class QpDTable(C.Structure):
                 ("symmetric", C.c_int32), ("reserved_", C.c_int32)]
 
 
-class QpQuboSeg(C.Structure):
-    _fields_ = [("mat", C.c_void_p), ("ld", C.c_int32), ("K", C.c_int32), ("xoff", C.c_int64)]
-
-
-class QpQuboDense(C.Structure):
-    _fields_ = [("T", C.c_int32), ("Npad", C.c_int32), ("constant", C.c_int32), ("pad_", C.c_int32),
-                ("segs", C.c_void_p), ("seg_ptr", C.c_void_p), ("tile_slice", C.c_void_p), ("off", C.c_void_p),
-                ("linear", C.c_void_p)]
+class QpQuboKron(C.Structure):
+    _fields_ = [("T", C.c_int32), ("C", C.c_int32), ("cap", C.c_int32), ("nmax", C.c_int32), ("Npad", C.c_int64),
+                ("constant", C.c_int32), ("n_tiles", C.c_int32),
+                ("n", C.c_void_p), ("pitch", C.c_void_p), ("off", C.c_void_p), ("same", C.c_void_p),
+                ("same_off", C.c_void_p), ("tile_slice", C.c_void_p), ("tile_first", C.c_void_p), ("linear", C.c_void_p),
+                ("next", C.c_void_p), ("prev", C.c_void_p), ("hops10", C.c_void_p)]
 
 
 class QpQuboStruct(C.Structure):
     _fields_ = [("T", C.c_int32), ("C", C.c_int32), ("cap", C.c_int32), ("nmax", C.c_int32), ("Npad", C.c_int64),
                 ("n", C.c_void_p), ("off", C.c_void_p), ("info", C.c_void_p), ("nbr_ptr", C.c_void_p),
-                ("nbr", C.c_void_p), ("hops", C.c_void_p)]
+                ("nbr", C.c_void_p), ("hops", C.c_void_p), ("pitch", C.c_void_p)]
 
 
 QP_QUBO_INIT_GIVEN = 1
@@ -117,8 +115,11 @@ EXPORTS = {
                                    C.c_void_p, C.c_void_p]),
     "qp_comm_matrix": (C.c_int, [C.POINTER(QpCircuit), C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                  C.c_void_p, C.c_void_p, C.c_void_p]),
-    "qp_qubo_fields_i32": (C.c_int, [C.POINTER(QpQuboDense), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
-    "qp_qubo_energy_i32": (C.c_int, [C.POINTER(QpQuboDense), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "qp_qubo_workspace": (C.c_size_t, [C.POINTER(QpQuboKron), C.c_int32]),
+    "qp_qubo_fields_i32": (C.c_int, [C.POINTER(QpQuboKron), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t,
+                                     C.c_void_p]),
+    "qp_qubo_energy_i32": (C.c_int, [C.POINTER(QpQuboKron), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t,
+                                     C.c_void_p]),
     "qp_qubo_anneal": (C.c_int, [C.POINTER(QpQuboStruct), C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_uint64,
                                  C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
 }

@@ -1,6 +1,12 @@
-// QUBO placer on gfx950: exact integer energies / local fields of R replica states by an int8 MFMA
-// contraction against the block-tridiagonal coefficient matrix, and replica-parallel simulated
-// annealing that works from the model's structure (no coefficient matrix) with one wave per replica.
+// QUBO placer on gfx950: exact integer energies / local fields of R replica states, and replica-parallel
+// simulated annealing that works from the model's structure with one wave per replica.
+//
+// The coefficient matrix of a timeslice is a Kronecker sum (variables v = j * P + k: core j, k-th variable
+// of the core):  I_C (x) same  +  (J - I)_C (x) diag(8 on the qubit rows),  and the coupling to the next slice
+// is 10 * hops (x) (matching of the qubits both slices have).  Only `same` (W x W, the same for every core)
+// is a dense matrix: it goes through an int8 MFMA contraction, one W x W x R product per core.  The other two
+// terms only ever couple the C bits "qubit k on core j": they are evaluated from one C-bit mask per (slice,
+// qubit, replica), which a small kernel extracts from the states first.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -14,33 +20,32 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
 // ------------------------------------------------------------------------------------------------
-// F = S . X  (and  sum_v x_v (2 a_v + F_v))  with v_mfma_i32_32x32x32_i8
+// F_same = same . X_j  (and  sum_v x_v (2 a_v + F_same_v))  with v_mfma_i32_32x32x32_i8
 //
-// Workgroup = 4 waves (2 x 2), tile = 128 variables x 128 replicas, each wave 64 x 64 as 2 x 2 MFMA
-// tiles.  Both operands are contiguous along the contraction axis (S row-major, states stored
-// replica-major), so a lane's A or B fragment is 16 consecutive bytes.  Tiles go through LDS with a
-// 144-byte row pitch: 16 consecutive rows then start in 16 different 16-byte slots of the 256-byte
-// bank row, which is what ds_read_b128 needs to run conflict-free.
+// Workgroup = 4 waves (2 x 2), tile = 128 rows of `same` x 64 WN replicas for one core of one slice.  Both
+// operands are contiguous along the contraction axis (`same` row-major, states stored replica-major), so a
+// lane's A or B fragment is 16 consecutive bytes.  Tiles go through LDS with a 144-byte row pitch: 16
+// consecutive rows then start in 16 different 16-byte slots of the 256-byte bank row, which is what
+// ds_read_b128 needs to run conflict-free.
 // ------------------------------------------------------------------------------------------------
 
 constexpr int kTile = 128;
 constexpr int kBK = 128;
 constexpr int kPitch = 144;  // 128 + 16: consecutive rows start 9 sixteen-byte slots apart (odd => conflict-free)
 
-struct GemmArgs {
-    const QpQuboSeg* segs;
-    const int32_t* seg_ptr;     // [T+1]
-    const int32_t* tile_slice;  // [row tiles]
-    const int64_t* off;         // [T+1] padded variable offset of each slice
-    const int8_t* Xt;           // [R][Npad]
-    const int32_t* linear;      // [Npad]
-    int32_t* out;               // fields: [Npad][R]; energy: [R] (accumulated with integer atomics)
-    int32_t Npad, R;
+struct KronArgs {
+    QpQuboKron m;
+    const int8_t* Xt;  // [R][Npad]
+    int32_t* out;      // fields: [Npad][R]; energy: [R] (accumulated with integer atomics)
+    uint32_t* masks;   // [T][nmax][R]: bit j = qubit on core j
+    int32_t R;
 };
 
 // What a workgroup does with its accumulators: store the fields, or fold them into the replicas' energies.
+// rows: the tile's first row inside the core's block (krow0), valid while < P; v0 = state index of row krow0.
 template <bool ENERGY, int WN>
-__device__ inline void gemm_epilogue(const GemmArgs& p, v16i (&acc)[2][WN], int64_t v0, int r0, int wm, int wn, int lane) {
+__device__ inline void kron_epilogue(const KronArgs& p, v16i (&acc)[2][WN], int64_t v0, int krow0, int P, int r0, int wm,
+                                     int wn, int lane) {
     // accumulator element k of lane l: row (k & 3) + 8 * (k >> 2) + 4 * (l >> 5), column l & 31
     const int h = lane >> 5;
     if constexpr (!ENERGY) {
@@ -51,8 +56,8 @@ __device__ inline void gemm_epilogue(const GemmArgs& p, v16i (&acc)[2][WN], int6
                 const int col = r0 + wn * 32 * WN + b * 32 + (lane & 31);
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
-                    const int64_t row = v0 + wm * 64 + a * 32 + (k & 3) + 8 * (k >> 2) + 4 * h;
-                    p.out[(size_t)row * p.R + col] = acc[a][b][k];
+                    const int i = wm * 64 + a * 32 + (k & 3) + 8 * (k >> 2) + 4 * h;
+                    if (krow0 + i < P) p.out[(size_t)(v0 + i) * p.R + col] = acc[a][b][k];
                 }
             }
     } else {
@@ -64,13 +69,15 @@ __device__ inline void gemm_epilogue(const GemmArgs& p, v16i (&acc)[2][WN], int6
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int64_t row = v0 + wm * 64 + a * 32 + 8 * g + 4 * h;
-                    const uint32_t x4 = *reinterpret_cast<const uint32_t*>(p.Xt + (size_t)col * p.Npad + row);
-                    const int4 lin = *reinterpret_cast<const int4*>(p.linear + row);
-                    const int l4[4] = {lin.x, lin.y, lin.z, lin.w};
+                    const int i = wm * 64 + a * 32 + 8 * g + 4 * h;  // four consecutive rows; P is a multiple of 32
+                    if (krow0 + i < P) {
+                        const uint32_t x4 = *reinterpret_cast<const uint32_t*>(p.Xt + (size_t)col * p.m.Npad + v0 + i);
+                        const int4 lin = *reinterpret_cast<const int4*>(p.m.linear + v0 + i);
+                        const int l4[4] = {lin.x, lin.y, lin.z, lin.w};
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if ((x4 >> (8 * j)) & 1u) s += 2 * l4[j] + acc[a][b][4 * g + j];
+                        for (int j = 0; j < 4; ++j)
+                            if ((x4 >> (8 * j)) & 1u) s += 2 * l4[j] + acc[a][b][4 * g + j];
+                    }
                 }
             s += __shfl_xor(s, 32, 64);
             if (h == 0) atomicAdd(&p.out[col], s);
@@ -81,16 +88,21 @@ __device__ inline void gemm_epilogue(const GemmArgs& p, v16i (&acc)[2][WN], int6
 // WN = MFMA tiles per wave along the replica axis: 2 (128 replicas per workgroup) or 4 (256).  With 4, a
 // wave feeds 8 MFMAs from 6 fragment reads instead of 4 from 4, which is what the LDS read rate allows.
 template <bool ENERGY, int WN>
-__global__ __launch_bounds__(256, 2) void k_qubo_gemm(GemmArgs p) {
+__global__ __launch_bounds__(256, 2) void k_qubo_kron(KronArgs p) {
     constexpr int kCols = 64 * WN;  // replicas per workgroup
     __shared__ __align__(16) int8_t sA[kTile * kPitch];
     __shared__ __align__(16) int8_t sB[kCols * kPitch];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int rowtile = blockIdx.y, coltile = blockIdx.x;  // the column tiles of one row tile run side by side: S is read from HBM once
-    const int t = p.tile_slice[rowtile];
-    const int64_t v0 = (int64_t)rowtile * kTile;     // first variable (padded axis) of this tile
-    const int64_t vrow = v0 - p.off[t];              // row inside the slice's blocks
+    const int tile = blockIdx.y, coltile = blockIdx.x;  // the replica tiles of one row tile run side by side
+    const int t = p.m.tile_slice[tile];
+    const int P = p.m.pitch[t];
+    const int Pp = (P + kTile - 1) / kTile * kTile;  // rows and row pitch of the slice's `same` matrix
+    const int MT = Pp / kTile;
+    const int local = tile - p.m.tile_first[t];
+    const int j = local / MT, mt = local - j * MT;
+    const int krow0 = mt * kTile;
+    const int64_t vcore = p.m.off[t] + (int64_t)j * P;  // first state byte of this core's variables
     const int r0 = coltile * kCols;
 
     v16i acc[2][WN];
@@ -102,77 +114,195 @@ __global__ __launch_bounds__(256, 2) void k_qubo_gemm(GemmArgs p) {
             for (int k = 0; k < 16; ++k) acc[a][b][k] = 0;
 
     // staging: thread -> (row = tid / 8 + 32 i, 16-byte piece = tid % 8) of a (rows x 128)-byte tile; the
-    // next tile's global loads are issued before the current tile's MFMAs so they overlap
+    // next tile's global loads are issued before the current tile's MFMAs so they overlap.  `same` is padded
+    // with zero columns up to Pp; the states are not read past the core's P bytes (zeros instead).
     const int srow = tid >> 3, spiece = tid & 7;
+    const int8_t* Ab = p.m.same + p.m.same_off[t] + (size_t)krow0 * Pp;
+    const int8_t* Bb = p.Xt + (size_t)r0 * p.m.Npad + vcore;
     // (named registers and a macro: staging arrays, or a lambda capturing them, end up in scratch memory)
     uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3, rb4, rb5, rb6, rb7;
-#define QP_LOAD_TILE(Ab, Bb, ld, k0)                                                                          \
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+#define QP_LOAD_TILE(k0)                                                                                       \
     do {                                                                                                      \
-        const int8_t* pa_ = (Ab) + (size_t)srow * (ld) + (k0) + spiece * 16;                                  \
-        const int8_t* pb_ = (Bb) + (size_t)srow * p.Npad + (k0) + spiece * 16;                                \
+        const int8_t* pa_ = Ab + (size_t)srow * Pp + (k0) + spiece * 16;                                      \
+        const int8_t* pb_ = Bb + (size_t)srow * p.m.Npad + (k0) + spiece * 16;                                \
+        const bool in_ = (k0) + spiece * 16 < P;                                                              \
         ra0 = *reinterpret_cast<const uint4*>(pa_);                                                           \
-        ra1 = *reinterpret_cast<const uint4*>(pa_ + (size_t)32 * (ld));                                       \
-        ra2 = *reinterpret_cast<const uint4*>(pa_ + (size_t)64 * (ld));                                       \
-        ra3 = *reinterpret_cast<const uint4*>(pa_ + (size_t)96 * (ld));                                       \
-        rb0 = *reinterpret_cast<const uint4*>(pb_);                                                           \
-        rb1 = *reinterpret_cast<const uint4*>(pb_ + (size_t)32 * p.Npad);                                     \
-        rb2 = *reinterpret_cast<const uint4*>(pb_ + (size_t)64 * p.Npad);                                     \
-        rb3 = *reinterpret_cast<const uint4*>(pb_ + (size_t)96 * p.Npad);                                     \
+        ra1 = *reinterpret_cast<const uint4*>(pa_ + (size_t)32 * Pp);                                         \
+        ra2 = *reinterpret_cast<const uint4*>(pa_ + (size_t)64 * Pp);                                         \
+        ra3 = *reinterpret_cast<const uint4*>(pa_ + (size_t)96 * Pp);                                         \
+        rb0 = in_ ? *reinterpret_cast<const uint4*>(pb_) : zero4;                                             \
+        rb1 = in_ ? *reinterpret_cast<const uint4*>(pb_ + (size_t)32 * p.m.Npad) : zero4;                     \
+        rb2 = in_ ? *reinterpret_cast<const uint4*>(pb_ + (size_t)64 * p.m.Npad) : zero4;                     \
+        rb3 = in_ ? *reinterpret_cast<const uint4*>(pb_ + (size_t)96 * p.m.Npad) : zero4;                     \
         if constexpr (WN == 4) {                                                                              \
-            rb4 = *reinterpret_cast<const uint4*>(pb_ + (size_t)128 * p.Npad);                                \
-            rb5 = *reinterpret_cast<const uint4*>(pb_ + (size_t)160 * p.Npad);                                \
-            rb6 = *reinterpret_cast<const uint4*>(pb_ + (size_t)192 * p.Npad);                                \
-            rb7 = *reinterpret_cast<const uint4*>(pb_ + (size_t)224 * p.Npad);                                \
+            rb4 = in_ ? *reinterpret_cast<const uint4*>(pb_ + (size_t)128 * p.m.Npad) : zero4;                \
+            rb5 = in_ ? *reinterpret_cast<const uint4*>(pb_ + (size_t)160 * p.m.Npad) : zero4;                \
+            rb6 = in_ ? *reinterpret_cast<const uint4*>(pb_ + (size_t)192 * p.m.Npad) : zero4;                \
+            rb7 = in_ ? *reinterpret_cast<const uint4*>(pb_ + (size_t)224 * p.m.Npad) : zero4;                \
         }                                                                                                     \
     } while (0)
-    for (int sg = p.seg_ptr[t]; sg < p.seg_ptr[t + 1]; ++sg) {
-        const QpQuboSeg seg = p.segs[sg];
-        const int8_t* Ab = seg.mat + (size_t)vrow * seg.ld;
-        const int8_t* Bb = p.Xt + (size_t)r0 * p.Npad + seg.xoff;
-        QP_LOAD_TILE(Ab, Bb, seg.ld, 0);
-        for (int k0 = 0; k0 < seg.K; k0 += kBK) {
-            __syncthreads();
-            {
-                int8_t* wa = sA + srow * kPitch + spiece * 16;
-                int8_t* wb = sB + srow * kPitch + spiece * 16;
-                *reinterpret_cast<uint4*>(wa) = ra0;
-                *reinterpret_cast<uint4*>(wa + 32 * kPitch) = ra1;
-                *reinterpret_cast<uint4*>(wa + 64 * kPitch) = ra2;
-                *reinterpret_cast<uint4*>(wa + 96 * kPitch) = ra3;
-                *reinterpret_cast<uint4*>(wb) = rb0;
-                *reinterpret_cast<uint4*>(wb + 32 * kPitch) = rb1;
-                *reinterpret_cast<uint4*>(wb + 64 * kPitch) = rb2;
-                *reinterpret_cast<uint4*>(wb + 96 * kPitch) = rb3;
-                if constexpr (WN == 4) {
-                    *reinterpret_cast<uint4*>(wb + 128 * kPitch) = rb4;
-                    *reinterpret_cast<uint4*>(wb + 160 * kPitch) = rb5;
-                    *reinterpret_cast<uint4*>(wb + 192 * kPitch) = rb6;
-                    *reinterpret_cast<uint4*>(wb + 224 * kPitch) = rb7;
-                }
-            }
-            __syncthreads();
-            if (k0 + kBK < seg.K) QP_LOAD_TILE(Ab, Bb, seg.ld, k0 + kBK);
-#pragma unroll
-            for (int kk = 0; kk < kBK / 32; ++kk) {
-                v4i fa[2], fb[WN];
-                const int koff = kk * 32 + (lane >> 5) * 16;
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-                    fa[a] = *reinterpret_cast<const v4i*>(sA + (wm * 64 + a * 32 + (lane & 31)) * kPitch + koff);
-#pragma unroll
-                for (int b = 0; b < WN; ++b)
-                    fb[b] = *reinterpret_cast<const v4i*>(sB + (wn * 32 * WN + b * 32 + (lane & 31)) * kPitch + koff);
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int b = 0; b < WN; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[a], fb[b], acc[a][b], 0, 0, 0);
+    QP_LOAD_TILE(0);
+    for (int k0 = 0; k0 < P; k0 += kBK) {
+        __syncthreads();
+        {
+            int8_t* wa = sA + srow * kPitch + spiece * 16;
+            int8_t* wb = sB + srow * kPitch + spiece * 16;
+            *reinterpret_cast<uint4*>(wa) = ra0;
+            *reinterpret_cast<uint4*>(wa + 32 * kPitch) = ra1;
+            *reinterpret_cast<uint4*>(wa + 64 * kPitch) = ra2;
+            *reinterpret_cast<uint4*>(wa + 96 * kPitch) = ra3;
+            *reinterpret_cast<uint4*>(wb) = rb0;
+            *reinterpret_cast<uint4*>(wb + 32 * kPitch) = rb1;
+            *reinterpret_cast<uint4*>(wb + 64 * kPitch) = rb2;
+            *reinterpret_cast<uint4*>(wb + 96 * kPitch) = rb3;
+            if constexpr (WN == 4) {
+                *reinterpret_cast<uint4*>(wb + 128 * kPitch) = rb4;
+                *reinterpret_cast<uint4*>(wb + 160 * kPitch) = rb5;
+                *reinterpret_cast<uint4*>(wb + 192 * kPitch) = rb6;
+                *reinterpret_cast<uint4*>(wb + 224 * kPitch) = rb7;
             }
         }
+        __syncthreads();
+        if (k0 + kBK < P) QP_LOAD_TILE(k0 + kBK);
+#pragma unroll
+        for (int kk = 0; kk < kBK / 32; ++kk) {
+            if (k0 + kk * 32 >= P) break;  // P is a multiple of 32: whole MFMA steps
+            v4i fa[2], fb[WN];
+            const int koff = kk * 32 + (lane >> 5) * 16;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+                fa[a] = *reinterpret_cast<const v4i*>(sA + (wm * 64 + a * 32 + (lane & 31)) * kPitch + koff);
+#pragma unroll
+            for (int b = 0; b < WN; ++b)
+                fb[b] = *reinterpret_cast<const v4i*>(sB + (wn * 32 * WN + b * 32 + (lane & 31)) * kPitch + koff);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < WN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[a], fb[b], acc[a][b], 0, 0, 0);
+        }
     }
-
 #undef QP_LOAD_TILE
-    gemm_epilogue<ENERGY, WN>(p, acc, v0, r0, wm, wn, lane);
+    kron_epilogue<ENERGY, WN>(p, acc, vcore + krow0, krow0, P, r0, wm, wn, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Core masks: masks[t][k][r] bit j = state byte of (slice t, core j, qubit k) of replica r.
+// Workgroup = (64 replicas, slice, 64 qubits): the 64-byte runs of every (replica, core) go through LDS
+// (pitch per replica C * 64 + 4: the lanes of a wave, one replica each, hit different banks) and every
+// thread assembles 16 masks of its replica; the masks of one qubit leave as 256 contiguous bytes.
+// ------------------------------------------------------------------------------------------------
+
+constexpr int kBitsK = 64;
+constexpr int kBitsR = 64;
+
+__global__ __launch_bounds__(256) void k_qubo_bits(KronArgs p) {
+    extern __shared__ __align__(16) uint8_t lds[];
+    const int t = blockIdx.y, k0 = blockIdx.z * kBitsK, r0 = blockIdx.x * kBitsR;
+    const int n = p.m.n[t], P = p.m.pitch[t], C = p.m.C;
+    if (k0 >= n) return;
+    const int rpitch = C * kBitsK + 4;
+    const int64_t vslice = p.m.off[t];
+    const int pieces = kBitsR * C * (kBitsK / 16);
+    for (int q = threadIdx.x; q < pieces; q += 256) {
+        const int piece = q & 3, j = (q >> 2) % C, r = (q >> 2) / C;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (k0 + piece * 16 < P)
+            v = *reinterpret_cast<const uint4*>(p.Xt + (size_t)(r0 + r) * p.m.Npad + vslice + (int64_t)j * P + k0 + piece * 16);
+        uint32_t* d = reinterpret_cast<uint32_t*>(lds + r * rpitch + j * kBitsK + piece * 16);
+        d[0] = v.x;
+        d[1] = v.y;
+        d[2] = v.z;
+        d[3] = v.w;
+    }
+    __syncthreads();
+    const int r = threadIdx.x & 63, kq = threadIdx.x >> 6;  // 16 qubits per thread
+    uint32_t mk[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) mk[i] = 0;
+    for (int j = 0; j < C; ++j) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(lds + r * rpitch + j * kBitsK + kq * 16);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint32_t x = src[w];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mk[4 * w + i] |= ((x >> (8 * i)) & 1u) << j;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int k = k0 + kq * 16 + i;
+        if (k < n) p.masks[((size_t)t * p.m.nmax + k) * p.R + r0 + r] = mk[i];
+    }
+}
+
+// sum over the set bits j of a, l of b of h[j * C + l]
+__device__ inline int hop_pairs(uint32_t a, uint32_t b, const int32_t* h, int C) {
+    int s = 0;
+    while (a) {
+        const int j = __builtin_ctz(a);
+        a &= a - 1;
+        uint32_t bb = b;
+        while (bb) {
+            s += h[j * C + __builtin_ctz(bb)];
+            bb &= bb - 1;
+        }
+    }
+    return s;
+}
+
+// The terms of sum_v x_v F_v that the `same` matrix does not hold, from the masks: a qubit on p cores adds
+// 8 p (p - 1) (same qubit, two cores), a qubit present in the next slice as well adds twice (once from each
+// end) 10 * hops over all pairs (core now, core then).  Thread = replica; block y = slice.
+__global__ __launch_bounds__(256) void k_qubo_extra_energy(KronArgs p) {
+    __shared__ int32_t h[32 * 32];
+    const int t = blockIdx.y, C = p.m.C;
+    for (int i = threadIdx.x; i < C * C; i += 256) h[i] = p.m.hops10[i];
+    __syncthreads();
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= p.R) return;
+    const int n = p.m.n[t];
+    const uint32_t* mk = p.masks + (size_t)t * p.m.nmax * p.R + r;
+    const uint32_t* mk_next = mk + (size_t)p.m.nmax * p.R;
+    const int32_t* nxt = p.m.next + (size_t)t * p.m.nmax;
+    const bool has_next = t + 1 < p.m.T;
+    int e = 0;
+    for (int k = 0; k < n; ++k) {
+        const uint32_t m = mk[(size_t)k * p.R];
+        const int pc = __popc(m);
+        e += 8 * pc * (pc - 1);
+        const int k2 = has_next ? nxt[k] : -1;
+        if (k2 >= 0 && m) e += 2 * hop_pairs(m, mk_next[(size_t)k2 * p.R], h, C);
+    }
+    atomicAdd(&p.out[r], e);
+}
+
+// The same terms of the local fields: F[(t, j, k)] += 8 (p - bit_j) + sum_l hops10[j][l] bit_l(next) +
+// sum_l hops10[l][j] bit_l(previous).  Thread = replica; block y = slice, z = 16 qubits.
+__global__ __launch_bounds__(256) void k_qubo_extra_fields(KronArgs p) {
+    __shared__ int32_t h[32 * 32];
+    const int t = blockIdx.y, C = p.m.C;
+    for (int i = threadIdx.x; i < C * C; i += 256) h[i] = p.m.hops10[i];
+    __syncthreads();
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    const int n = p.m.n[t], P = p.m.pitch[t];
+    if (r >= p.R) return;
+    const uint32_t* mk = p.masks + (size_t)t * p.m.nmax * p.R + r;
+    for (int k = blockIdx.z * 16; k < min(n, (int)blockIdx.z * 16 + 16); ++k) {
+        const uint32_t m = mk[(size_t)k * p.R];
+        const int pc = __popc(m);
+        const int k2 = t + 1 < p.m.T ? p.m.next[(size_t)t * p.m.nmax + k] : -1;
+        const int k0 = t > 0 ? p.m.prev[(size_t)t * p.m.nmax + k] : -1;
+        const uint32_t mn = k2 >= 0 ? mk[((size_t)p.m.nmax + k2) * p.R] : 0u;
+        const uint32_t mp = k0 >= 0 ? *(mk - (size_t)p.m.nmax * p.R + (size_t)k0 * p.R) : 0u;
+        for (int j = 0; j < C; ++j) {
+            int v = 8 * (pc - (int)((m >> j) & 1u));
+            for (uint32_t b = mn; b; b &= b - 1) v += h[j * C + __builtin_ctz(b)];
+            for (uint32_t b = mp; b; b &= b - 1) v += h[__builtin_ctz(b) * C + j];
+            p.out[(size_t)(p.m.off[t] + (int64_t)j * P + k) * p.R + r] += v;
+        }
+    }
 }
 
 // energy2[r] -> constant + energy2[r] / 2
@@ -248,7 +378,7 @@ __global__ __launch_bounds__(256) void k_qubo_anneal(SaArgs p) {
     if (lane == 0) mask[(size_t)T * nmax] = 0;
     for (int t = 0; t < T; ++t) {
         const int n = m.n[t];
-        const int W = n + cap;
+        const int W = m.pitch[t];  // state bytes per core: the n qubit bits, the cap slack bits, padding
         const int8_t* Xs = X + m.off[t];
         for (int i = lane; i < nmax; i += 64) {
             uint32_t bits = 0;
@@ -371,14 +501,15 @@ __global__ __launch_bounds__(256) void k_qubo_anneal(SaArgs p) {
     // ---- write the state back (padding bytes are zeroed) and the summed energy change
     for (int t = 0; t < T; ++t) {
         const int n = m.n[t];
-        const int W = n + cap;
+        const int W = m.pitch[t];
         int8_t* Xs = X + m.off[t];
         const int64_t total = m.off[t + 1] - m.off[t];
         for (int64_t v = lane; v < total; v += 64) {
             int8_t val = 0;
             if (v < (int64_t)C * W) {
                 const int j = (int)(v / W), kx = (int)(v - (int64_t)j * W);
-                val = kx < n ? (int8_t)((mask[t * nmax + kx] >> j) & 1u) : (int8_t)((slack[t * C + j] >> (kx - n)) & 1u);
+                if (kx < n) val = (int8_t)((mask[t * nmax + kx] >> j) & 1u);
+                else if (kx < n + cap) val = (int8_t)((slack[t * C + j] >> (kx - n)) & 1u);
             }
             Xs[v] = val;
         }
@@ -388,48 +519,72 @@ __global__ __launch_bounds__(256) void k_qubo_anneal(SaArgs p) {
     if (lane == 0) p.dE[r] = dEsum;
 }
 
-int check_dense(const char* fn, const QpQuboDense* m, const int8_t* Xt, int32_t R, const void* out) {
+int check_kron(const char* fn, const QpQuboKron* m, const int8_t* Xt, int32_t R, const void* out, const void* ws,
+               size_t ws_bytes) {
     if (!m || !Xt || !out) return qp::fail(QP_EINVAL, "%s: null argument", fn);
     if (m->T <= 0 || m->Npad <= 0 || m->Npad % kTile) return qp::fail(QP_EINVAL, "%s: Npad must be a positive multiple of 128", fn);
+    if (m->C <= 0 || m->C > 32 || m->cap <= 0 || m->cap > 32 || m->nmax <= 0) return qp::fail(QP_EINVAL, "%s: needs 1..32 cores and capacity 1..32", fn);
     if (R <= 0 || R % kTile) return qp::fail(QP_EINVAL, "%s: R must be a positive multiple of 128", fn);
-    if (!m->segs || !m->seg_ptr || !m->tile_slice || !m->off || !m->linear) return qp::fail(QP_EINVAL, "%s: model tables missing", fn);
+    if (!m->n || !m->pitch || !m->off || !m->same || !m->same_off || !m->tile_slice || !m->tile_first || !m->linear ||
+        !m->next || !m->prev || !m->hops10)
+        return qp::fail(QP_EINVAL, "%s: model tables missing", fn);
+    const size_t need = (size_t)m->T * m->nmax * R * sizeof(uint32_t);
+    if (!ws || ws_bytes < need) return qp::fail(QP_ENOSPC, "%s: workspace needs %zu bytes", fn, need);
+    if (reinterpret_cast<uintptr_t>(ws) % 16 || reinterpret_cast<uintptr_t>(Xt) % 16) return qp::fail(QP_EINVAL, "%s: states and workspace must be 16-byte aligned", fn);
     return QP_OK;
 }
 
-GemmArgs gemm_args(const QpQuboDense* m, const int8_t* Xt, int32_t R, int32_t* out) {
-    GemmArgs a{};
-    a.segs = m->segs;
-    a.seg_ptr = m->seg_ptr;
-    a.tile_slice = m->tile_slice;
-    a.off = m->off;
+KronArgs kron_args(const QpQuboKron* m, const int8_t* Xt, int32_t R, int32_t* out, void* ws) {
+    KronArgs a{};
+    a.m = *m;
     a.Xt = Xt;
-    a.linear = m->linear;
     a.out = out;
-    a.Npad = m->Npad;
+    a.masks = static_cast<uint32_t*>(ws);
     a.R = R;
     return a;
 }
 
-}  // namespace
-
-extern "C" int qp_qubo_fields_i32(const QpQuboDense* m, const int8_t* Xt, int32_t R, int32_t* F, void* stream_) {
-    if (int rc = check_dense("qp_qubo_fields_i32", m, Xt, R, F)) return rc;
-    if (R % 256 == 0)
-        k_qubo_gemm<false, 4><<<dim3(R / 256, m->Npad / kTile), 256, 0, static_cast<hipStream_t>(stream_)>>>(gemm_args(m, Xt, R, F));
-    else
-        k_qubo_gemm<false, 2><<<dim3(R / 128, m->Npad / kTile), 256, 0, static_cast<hipStream_t>(stream_)>>>(gemm_args(m, Xt, R, F));
+int launch_bits(const KronArgs& a, hipStream_t stream) {
+    const size_t lds = (size_t)kBitsR * (a.m.C * kBitsK + 4);
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_qubo_bits), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    k_qubo_bits<<<dim3(a.R / kBitsR, a.m.T, (a.m.nmax + kBitsK - 1) / kBitsK), 256, lds, stream>>>(a);
     HIP_TRY(hipGetLastError());
     return QP_OK;
 }
 
-extern "C" int qp_qubo_energy_i32(const QpQuboDense* m, const int8_t* Xt, int32_t R, int32_t* energy, void* stream_) {
-    if (int rc = check_dense("qp_qubo_energy_i32", m, Xt, R, energy)) return rc;
+}  // namespace
+
+extern "C" size_t qp_qubo_workspace(const QpQuboKron* m, int32_t R) {
+    if (!m || R <= 0 || m->T <= 0 || m->nmax <= 0) return 16;
+    return (size_t)m->T * m->nmax * R * sizeof(uint32_t);
+}
+
+extern "C" int qp_qubo_fields_i32(const QpQuboKron* m, const int8_t* Xt, int32_t R, int32_t* F, void* ws, size_t ws_bytes,
+                                  void* stream_) {
+    if (int rc = check_kron("qp_qubo_fields_i32", m, Xt, R, F, ws, ws_bytes)) return rc;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const KronArgs a = kron_args(m, Xt, R, F, ws);
+    HIP_TRY(hipMemsetAsync(F, 0, (size_t)m->Npad * R * sizeof(int32_t), stream));  // padding rows are never written
+    if (int rc = launch_bits(a, stream)) return rc;
+    if (R % 256 == 0) k_qubo_kron<false, 4><<<dim3(R / 256, m->n_tiles), 256, 0, stream>>>(a);
+    else k_qubo_kron<false, 2><<<dim3(R / 128, m->n_tiles), 256, 0, stream>>>(a);
+    HIP_TRY(hipGetLastError());
+    k_qubo_extra_fields<<<dim3((R + 255) / 256, m->T, (m->nmax + 15) / 16), 256, 0, stream>>>(a);
+    HIP_TRY(hipGetLastError());
+    return QP_OK;
+}
+
+extern "C" int qp_qubo_energy_i32(const QpQuboKron* m, const int8_t* Xt, int32_t R, int32_t* energy, void* ws,
+                                  size_t ws_bytes, void* stream_) {
+    if (int rc = check_kron("qp_qubo_energy_i32", m, Xt, R, energy, ws, ws_bytes)) return rc;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const KronArgs a = kron_args(m, Xt, R, energy, ws);
     HIP_TRY(hipMemsetAsync(energy, 0, (size_t)R * sizeof(int32_t), stream));
-    if (R % 256 == 0)
-        k_qubo_gemm<true, 4><<<dim3(R / 256, m->Npad / kTile), 256, 0, stream>>>(gemm_args(m, Xt, R, energy));
-    else
-        k_qubo_gemm<true, 2><<<dim3(R / 128, m->Npad / kTile), 256, 0, stream>>>(gemm_args(m, Xt, R, energy));
+    if (int rc = launch_bits(a, stream)) return rc;
+    if (R % 256 == 0) k_qubo_kron<true, 4><<<dim3(R / 256, m->n_tiles), 256, 0, stream>>>(a);
+    else k_qubo_kron<true, 2><<<dim3(R / 128, m->n_tiles), 256, 0, stream>>>(a);
+    HIP_TRY(hipGetLastError());
+    k_qubo_extra_energy<<<dim3((R + 255) / 256, m->T), 256, 0, stream>>>(a);
     HIP_TRY(hipGetLastError());
     k_qubo_finish<<<(R + 255) / 256, 256, 0, stream>>>(energy, R, m->constant);
     HIP_TRY(hipGetLastError());
@@ -442,7 +597,7 @@ extern "C" int qp_qubo_anneal(const QpQuboStruct* m, int32_t R, int32_t sweeps, 
     if (m->T <= 0 || m->C <= 0 || m->C > 32 || m->cap <= 0 || m->cap > 32 || m->nmax <= 0)
         return qp::fail(QP_EINVAL, "qp_qubo_anneal: needs 1..32 cores and capacity 1..32");
     if (R <= 0 || sweeps < 0 || !(beta_hot > 0) || !(beta_cold > 0)) return qp::fail(QP_EINVAL, "qp_qubo_anneal: bad R/sweeps/beta");
-    if (!m->n || !m->off || !m->info || !m->nbr_ptr || !m->hops)
+    if (!m->n || !m->off || !m->info || !m->nbr_ptr || !m->hops || !m->pitch)
         return qp::fail(QP_EINVAL, "qp_qubo_anneal: model tables missing");
     if ((int64_t)m->T * m->nmax > 65534)
         return qp::fail(QP_EINVAL, "qp_qubo_anneal: T * nmax must stay below 65535 (16-bit word indices in info)");

@@ -11,13 +11,19 @@ Objective (weights Qubo_placer.py:29-32):
 Every coefficient is an integer, so energies are exact in int32.
 
 Written as  E(s) = const + sum_v a_v s_v + sum_{v<w} S_vw s_v s_w  with S symmetric, zero diagonal:
-    same qubit, two cores          S = +8            a(x) = 10 * deg_i
-    same core, two qubits          S = +8 (-20 more if they interact)
-    same core, two slack bits      S = +8            a(y) = +4
-    same core, qubit and slack     S = -8            const = 4 * (active qubits) per slice
+    same core, two qubits          S = +8 (-20 more if they interact)      a(x) = 10 * deg_i
+    same core, two slack bits      S = +8                                  a(y) = +4
+    same core, qubit and slack     S = -8                                  const = 4 * (active qubits) per slice
+    same qubit, two cores          S = +8
     same qubit in t and t+1        S = 10 * hops[j, l]
-Variable order inside a slice: v = j * (n_t + cap) + k, k < n_t for x, k >= n_t for y.  Each slice's
-block is padded to a multiple of 128 variables so the MFMA contraction needs no edge handling.
+The slice's matrix is a Kronecker sum: the ``same core`` couplings are one W x W matrix (W = n_t + cap)
+repeated for every core, the ``same qubit`` couplings a diagonal repeated for every pair of cores, and the
+coupling between slices a permutation of matching qubits times the C x C hop matrix.  Only the W x W
+matrix goes through the MFMA contraction; the other two are evaluated from per-qubit core bit masks.
+
+Variable order inside a slice: v = off[t] + j * P_t + k, k < n_t for x, n_t <= k < W for y, with the
+per-core pitch P_t = W rounded up to 32 (the rest is padding that stays zero); each slice's block is padded
+to a multiple of 128 variables.
 """
 from __future__ import annotations
 
@@ -26,6 +32,7 @@ import math
 import numpy as np
 
 PAD = 128
+PITCH = 32
 A_ASSIGN, B_CAP, C_LAP, D_MOVE = 4, 4, 10, 10
 
 
@@ -61,10 +68,11 @@ class QuboModel:
             self.deg.append(deg)
         self.n = np.array([len(a) for a in self.act], np.int32)
         self.W = self.n + self.cap                      # variables per core in slice t
-        self.Nt = self.C * self.W                       # variables in slice t
+        self.P = (self.W + PITCH - 1) // PITCH * PITCH  # their pitch in the state vector
+        self.Nt = self.C * self.P                       # state bytes of slice t (padding inside included)
         self.Np = (self.Nt + PAD - 1) // PAD * PAD      # padded
         self.off = np.concatenate([[0], np.cumsum(self.Np)]).astype(np.int64)
-        self.N = int(self.Nt.sum())
+        self.N = int((self.C * self.W).sum())           # binary variables of the model
         self.Npad = int(self.off[-1])
         self.const = int(A_ASSIGN * self.n.sum())
         # same qubit in the next slice: nxt[t][i] = local index in slice t+1 or -1
@@ -83,26 +91,36 @@ class QuboModel:
 
     # -- index helpers ----------------------------------------------------------------------------
     def var_x(self, t, j, i):
-        return int(self.off[t] + j * self.W[t] + i)
+        return int(self.off[t] + j * self.P[t] + i)
 
     def var_y(self, t, j, p):
-        return int(self.off[t] + j * self.W[t] + self.n[t] + p)
+        return int(self.off[t] + j * self.P[t] + self.n[t] + p)
 
-    # -- dense tables for the contraction -----------------------------------------------------------
+    # -- tables for the contraction ------------------------------------------------------------------
+    def real_mask(self) -> np.ndarray:
+        """bool [Npad]: which positions of the padded state vector are variables of the model."""
+        m = np.zeros(self.Npad, bool)
+        for t in range(self.T):
+            blk = np.zeros((self.C, int(self.P[t])), bool)
+            blk[:, :int(self.W[t])] = True
+            m[self.off[t]:self.off[t] + self.Nt[t]] = blk.reshape(-1)
+        return m
+
     def linear(self) -> np.ndarray:
         """a_v over the padded variable axis (int32)."""
         a = np.zeros(self.Npad, np.int32)
         for t in range(self.T):
-            n, W = int(self.n[t]), int(self.W[t])
-            blk = np.zeros((self.C, W), np.int32)
+            n, W, P = int(self.n[t]), int(self.W[t]), int(self.P[t])
+            blk = np.zeros((self.C, P), np.int32)
             blk[:, :n] = C_LAP * self.deg[t][None, :]
-            blk[:, n:] = B_CAP
+            blk[:, n:W] = B_CAP
             a[self.off[t]:self.off[t] + self.Nt[t]] = blk.reshape(-1)
         return a
 
-    def slice_block(self, t) -> np.ndarray:
-        """S restricted to slice t: int8 [Np_t, Np_t], symmetric, zero diagonal."""
-        n, W, C = int(self.n[t]), int(self.W[t]), self.C
+    def same_core_block(self, t) -> np.ndarray:
+        """The couplings between the W variables of one core in slice t (the same for every core): int8,
+        zero diagonal, padded with zeros to [rows: P_t up to 128][columns: P_t up to 128]."""
+        n, W, P = int(self.n[t]), int(self.W[t]), int(self.P[t])
         same = np.full((W, W), 2 * B_CAP, np.int32)
         same[:n, n:] = -2 * B_CAP
         same[n:, :n] = -2 * B_CAP
@@ -110,36 +128,26 @@ class QuboModel:
             same[a, b] -= 2 * C_LAP
             same[b, a] -= 2 * C_LAP
         np.fill_diagonal(same, 0)
-        cross = np.zeros((W, W), np.int32)
-        cross[np.arange(n), np.arange(n)] = 2 * A_ASSIGN
-        eye = np.eye(C, dtype=np.int32)
-        S = np.kron(eye, same) + np.kron(1 - eye, cross)
-        out = np.zeros((int(self.Np[t]), int(self.Np[t])), np.int8)
-        assert np.abs(S).max() <= 127
-        out[:S.shape[0], :S.shape[1]] = S
+        assert np.abs(same).max() <= 127
+        Pp = (P + PAD - 1) // PAD * PAD
+        out = np.zeros((Pp, Pp), np.int8)
+        out[:W, :W] = same
         return out
 
-    def move_layers(self, t):
-        """The coupling between slice t (rows) and t+1 (columns), 10 * hops on matching qubits, as a
-        list of int8 [Np_t, Np_{t+1}] layers whose sum is the block (one layer when 10*hops <= 127)."""
-        n0, n1, W0, W1, C = int(self.n[t]), int(self.n[t + 1]), int(self.W[t]), int(self.W[t + 1]), self.C
-        P = np.zeros((W0, W1), np.int32)
-        for i in range(n0):
-            k = self.nxt[t][i]
-            if k >= 0:
-                P[i, k] = 1
-        full = np.kron(D_MOVE * self.H.astype(np.int32), P)
-        layers = []
-        rest = full
-        while True:
-            part = np.minimum(rest, 127)
-            out = np.zeros((int(self.Np[t]), int(self.Np[t + 1])), np.int8)
-            out[:full.shape[0], :full.shape[1]] = part
-            layers.append(out)
-            rest = rest - part
-            if not rest.any():
-                break
-        return layers
+    def coupling_counts(self):
+        """(non-zero couplings S_vw, ordered pairs; multiply-accumulates per replica the MFMA contraction runs;
+        what a dense contraction of the whole block-tridiagonal matrix would run)."""
+        nnz = mfma = dense = 0
+        for t in range(self.T):
+            n, W, P, C = int(self.n[t]), int(self.W[t]), int(self.P[t]), self.C
+            nnz += C * (W * W - W) + n * C * (C - 1)
+            Pp = (P + PAD - 1) // PAD * PAD
+            mfma += C * Pp * P
+            width = int(self.Np[t]) + (int(self.Np[t + 1]) if t + 1 < self.T else 0) + (int(self.Np[t - 1]) if t > 0 else 0)
+            dense += int(self.Np[t]) * width
+            if t + 1 < self.T:
+                nnz += 2 * int((self.nxt[t] >= 0).sum()) * int((self.H != 0).sum())
+        return nnz, mfma, dense
 
     # -- states -----------------------------------------------------------------------------------
     def state_from_rows(self, rows, slack="fill") -> np.ndarray:
@@ -166,8 +174,8 @@ class QuboModel:
         least-loaded core (first minimum).  Returns T rows of length Q with None for inactive qubits."""
         rows = []
         for t in range(self.T):
-            n, W = int(self.n[t]), int(self.W[t])
-            blk = state[self.off[t]:self.off[t] + self.Nt[t]].reshape(self.C, W)[:, :n]
+            n, P = int(self.n[t]), int(self.P[t])
+            blk = state[self.off[t]:self.off[t] + self.Nt[t]].reshape(self.C, P)[:, :n]
             row = [None] * self.ir.Q
             load = [0] * self.C
             pending = []
@@ -203,7 +211,7 @@ class QuboModel:
 class DeviceQubo:
     """A QuboModel uploaded to one GPU, plus the three device entry points of the QUBO path."""
 
-    def __init__(self, model: QuboModel, device=None, dense=True):
+    def __init__(self, model: QuboModel, device=None):
         import ctypes as C
         import torch
         from . import _lib
@@ -213,40 +221,38 @@ class DeviceQubo:
         self.device = device if device is not None else default_device()
         dev = self.device
         self._keep = []
+        self._ws = None
 
         def up(arr):
             t = torch.from_numpy(np.ascontiguousarray(arr)).to(dev)
             self._keep.append(t)
             return t
 
+        if m.C > 32 or m.cap > 32:
+            raise ValueError("the QUBO kernels keep a core mask per qubit and a slack mask per core: at most 32 cores, capacity 32")
         off = up(m.off.astype(np.int64))
-        self.dense = None
-        if dense:
-            segs, seg_ptr = [], [0]
-            move = [m.move_layers(t) for t in range(m.T - 1)]
-            for t in range(m.T):
-                blk = up(m.slice_block(t))
-                segs.append((blk.data_ptr(), int(m.Np[t]), int(m.Np[t]), int(m.off[t])))
-                if t + 1 < m.T:
-                    for layer in move[t]:
-                        d = up(layer)
-                        segs.append((d.data_ptr(), int(m.Np[t + 1]), int(m.Np[t + 1]), int(m.off[t + 1])))
-                if t > 0:
-                    for layer in move[t - 1]:
-                        d = up(np.ascontiguousarray(layer.T))
-                        segs.append((d.data_ptr(), int(m.Np[t - 1]), int(m.Np[t - 1]), int(m.off[t - 1])))
-                seg_ptr.append(len(segs))
-            seg_arr = (_lib.QpQuboSeg * len(segs))(*[_lib.QpQuboSeg(*s) for s in segs])
-            seg_dev = up(np.frombuffer(bytes(seg_arr), np.uint8).copy())
-            tile_slice = np.repeat(np.arange(m.T, dtype=np.int32), (m.Np // PAD).astype(np.int64))
-            self.dense = _lib.QpQuboDense(m.T, m.Npad, m.const, 0, seg_dev.data_ptr(),
-                                          up(np.asarray(seg_ptr, np.int32)).data_ptr(), up(tile_slice).data_ptr(),
-                                          off.data_ptr(), up(m.linear()).data_ptr())
-            self.dense_bytes = sum(int(t.numel() * t.element_size()) for t in self._keep)
         nmax = int(max(1, m.n.max()))
-        deg = np.zeros((m.T, nmax), np.uint8)
+        blocks = [m.same_core_block(t) for t in range(m.T)]
+        same_off = np.concatenate([[0], np.cumsum([b.size for b in blocks])]).astype(np.int64)
+        same = up(np.concatenate([b.reshape(-1) for b in blocks]) if blocks else np.zeros(1, np.int8))
+        row_tiles = np.array([b.shape[0] // PAD for b in blocks], np.int32)        # 128-row tiles of the W x W block
+        tile_first = np.concatenate([[0], np.cumsum(m.C * row_tiles)]).astype(np.int32)
+        tile_slice = np.repeat(np.arange(m.T, dtype=np.int32), (m.C * row_tiles).astype(np.int64))
+        nxt = np.full((m.T, nmax), -1, np.int32)
+        prv = np.full((m.T, nmax), -1, np.int32)
+        for t in range(m.T):
+            nxt[t, :int(m.n[t])] = m.nxt[t]
+            prv[t, :int(m.n[t])] = m.prv[t]
+        self.kron = _lib.QpQuboKron(
+            m.T, m.C, m.cap, nmax, m.Npad, m.const, int(tile_first[-1]),
+            up(m.n.astype(np.int32)).data_ptr(), up(m.P.astype(np.int32)).data_ptr(), off.data_ptr(),
+            same.data_ptr(), up(same_off).data_ptr(), up(tile_slice if len(tile_slice) else np.zeros(1, np.int32)).data_ptr(),
+            up(tile_first).data_ptr(), up(m.linear()).data_ptr(), up(nxt).data_ptr(), up(prv).data_ptr(),
+            up((D_MOVE * m.H).astype(np.int32)).data_ptr())
+        self.model_bytes = sum(int(t.numel() * t.element_size()) for t in self._keep)
         nxt = np.full((m.T, nmax), -1, np.int16)
         prv = np.full((m.T, nmax), -1, np.int16)
+        deg = np.zeros((m.T, nmax), np.uint8)
         ptr = np.zeros(m.T * nmax + 1, np.int32)
         nbr = []
         for t in range(m.T):
@@ -281,7 +287,7 @@ class DeviceQubo:
         self.struct = _lib.QpQuboStruct(m.T, m.C, m.cap, nmax, m.Npad, up(m.n.astype(np.int32)).data_ptr(),
                                         off.data_ptr(), up(info).data_ptr(), up(ptr).data_ptr(),
                                         up(np.asarray(nbr if nbr else [0], np.int16)).data_ptr(),
-                                        up(m.H.astype(np.uint8)).data_ptr())
+                                        up(m.H.astype(np.uint8)).data_ptr(), up(m.P.astype(np.int32)).data_ptr())
 
     def _stream(self):
         return self._C.c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
@@ -292,22 +298,30 @@ class DeviceQubo:
             raise ValueError("states must be a contiguous int8 [R, Npad] tensor")
         return Xt.shape[0]
 
+    def _workspace(self, R):
+        need = int(self._lib.lib().qp_qubo_workspace(self._C.byref(self.kron), R))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = self._torch.empty(need, dtype=self._torch.uint8, device=self.device)
+        return self._ws
+
     def energy(self, Xt):
         """Exact energies (int32 [R]) of replica states Xt (int8 [R, Npad], R % 128 == 0)."""
         R = self._check_states(Xt)
         out = self._torch.empty(R, dtype=self._torch.int32, device=self.device)
+        ws = self._workspace(R)
         with self._torch.cuda.device(self.device):
-            self._lib.check(self._lib.lib().qp_qubo_energy_i32(self._C.byref(self.dense), Xt.data_ptr(), R,
-                                                               out.data_ptr(), self._stream()))
+            self._lib.check(self._lib.lib().qp_qubo_energy_i32(self._C.byref(self.kron), Xt.data_ptr(), R,
+                                                               out.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()))
         return out
 
     def fields(self, Xt):
         """Local fields F[v, r] (int32 [Npad, R])."""
         R = self._check_states(Xt)
         out = self._torch.empty((self.model.Npad, R), dtype=self._torch.int32, device=self.device)
+        ws = self._workspace(R)
         with self._torch.cuda.device(self.device):
-            self._lib.check(self._lib.lib().qp_qubo_fields_i32(self._C.byref(self.dense), Xt.data_ptr(), R,
-                                                               out.data_ptr(), self._stream()))
+            self._lib.check(self._lib.lib().qp_qubo_fields_i32(self._C.byref(self.kron), Xt.data_ptr(), R,
+                                                               out.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()))
         return out
 
     def anneal(self, R, sweeps, seed=42, beta=None, init=None):

@@ -582,3 +582,46 @@ def test_place_batch_with_a_table_per_instance(pname):
             assert (got[s] == np.array(rows)).all(), (pname, s)
     finally:
         arch.network = intact
+
+
+_RCCL_WORKER = """
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np
+import torch
+import torch.distributed as dist
+from quantum_simulator_amd import driver
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+assert dist.get_backend() == "nccl"
+sums = np.array([[[30.0, 2, 1.0, 2]], [[0.0, 0, 0.25, 1]]])
+mins = np.array([[10.0], [np.inf]])
+# world size 1 short-circuits in reduce_table: run the two collectives it would run, on device tensors
+s = torch.from_numpy(sums).to("cuda")
+m = torch.from_numpy(mins).to("cuda")
+dist.all_reduce(s, op=dist.ReduceOp.SUM)
+dist.all_reduce(m, op=dist.ReduceOp.MIN)
+torch.cuda.synchronize()
+assert s.cpu().numpy().tobytes() == sums.tobytes() and m.cpu().numpy().tobytes() == mins.tobytes()
+s2, m2 = driver.reduce_table(sums, mins, torch.device("cuda", 0))
+assert s2.tobytes() == sums.tobytes() and m2.tobytes() == mins.tobytes()
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL ok")
+"""
+
+
+def test_rccl_all_reduce_of_the_result_table(tmp_path):
+    """The job's only collectives (one SUM and one MIN all-reduce of a few doubles) through the RCCL backend on
+    device tensors.  One GPU is all a test box has, so the group has one rank: what runs is RCCL's
+    initialisation and the two all-reduce calls the driver makes; the two-rank logic is covered on gloo."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "w.py"
+    script.write_text(_RCCL_WORKER.format(root=root))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29581", RANK="0", WORLD_SIZE="1")
+    out = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                         timeout=280)
+    assert out.returncode == 0 and "RCCL ok" in out.stdout, out.stdout

@@ -56,9 +56,7 @@ def test_energy_and_fields_exact(gpu, Q, T, C, cap, seed):
     rng = np.random.default_rng(seed)
     R = 128
     X = np.zeros((R, qm.Npad), np.int8)
-    real = np.zeros(qm.Npad, bool)
-    for t in range(qm.T):
-        real[qm.off[t]:qm.off[t] + qm.Nt[t]] = True
+    real = qm.real_mask()
     X[:, real] = rng.integers(0, 2, size=(R, int(real.sum())))
     X[0] = 0
     X[1, real] = 1
@@ -124,10 +122,7 @@ def test_anneal_bookkeeping_and_quality(gpu, Q, T, C, cap, seed):
     # continuing from given states works and padding stays zero
     X3, d3 = dq.anneal(R, 50, seed=11, init=X1)
     assert torch.equal(dq.energy(X3) - e1, d3)
-    pad = np.ones(qm.Npad, bool)
-    for t in range(qm.T):
-        pad[qm.off[t]:qm.off[t] + qm.Nt[t]] = False
-    assert int(X3.cpu().numpy()[:, pad].sum()) == 0
+    assert int(X3.cpu().numpy()[:, ~qm.real_mask()].sum()) == 0
     # quality: annealing beats both its random start and the block placement (active qubit i of each
     # slice on core i // cap, slack bits filled), which satisfies every constraint
     rows0 = []
@@ -258,10 +253,10 @@ def test_three_qubit_gate_couples_all_pairs(gpu):
         assert _oracle_energy(qm, names, s)[0] == want
 
 
-def test_long_moves_split_into_int8_layers(gpu):
-    """A coupling of 10 * hops above 127 does not fit one int8 matrix: on a line of 15 cores a qubit that is
-    on core 0 in slice 0 and on core 14 in slice 1 costs 10 * 14 = 140 and nothing else (one-hot, slack bit
-    set); moving it to core 13 costs 130, to core 12 120 (one layer suffices there)."""
+def test_long_moves_beyond_int8(gpu):
+    """A coupling of 10 * hops above 127 (more than an int8 matrix entry holds): on a line of 15 cores a qubit
+    that is on core 0 in slice 0 and on core 14 in slice 1 costs 10 * 14 = 140 and nothing else (one-hot, slack
+    bit set); moving it to core 13 costs 130, to core 12 120."""
     torch, dev = gpu
     from quantum_simulator_amd.engine import hops
     from quantum_simulator_amd.qubo import DeviceQubo, QuboModel
@@ -272,14 +267,14 @@ def test_long_moves_split_into_int8_layers(gpu):
     H = hops(C, list(range(C - 1)), list(range(1, C)))
     assert H[0, 14] == 14
     qm = QuboModel(ir, C, 1, H, ["q[0]"])
-    assert len(qm.move_layers(0)) == 2
+    assert 10 * int(qm.H.max()) > 127  # more than an int8 coefficient holds
     dq = DeviceQubo(qm, dev)
     states = [qm.state_from_rows([[0], [c]]) for c in (14, 13, 12, 0)]
     e = _energy_of(dq, qm, torch, dev, states)
     assert e.tolist() == [140, 130, 120, 0]
     for s, want in zip(states, (140, 130, 120, 0)):
         assert _oracle_energy(qm, ["q[0]"], s)[0] == want
-    # the local field of the slice-1 bit on core 14 sees the slice-0 bit through both layers
+    # the local field of the slice-1 bit on core 14 sees the slice-0 bit
     X = np.zeros((128, qm.Npad), np.int8)
     X[0] = states[0]
     F = dq.fields(torch.from_numpy(X).to(dev)).cpu().numpy()
@@ -337,12 +332,10 @@ def test_benchmark_size_model(gpu):
     nodes, eu, ev, _ = graph_tables(build_topology("mesh", 4, 4))
     names = [f"q[{i}]" for i in range(Q)]
     qm = QuboModel(ir, len(nodes), cap, hops(len(nodes), eu, ev), names)
-    assert qm.N == 35328 and qm.Npad == 8 * 4480
+    assert qm.N == 35328 and qm.Npad == 8 * 4608 and int(qm.P[0]) == 288
     dq = DeviceQubo(qm, dev)
     rng = np.random.default_rng(7)
-    real = np.zeros(qm.Npad, bool)
-    for t in range(qm.T):
-        real[qm.off[t]:qm.off[t] + qm.Nt[t]] = True
+    real = qm.real_mask()
     X0, d0 = dq.anneal(R, 0, seed=5)          # the annealer's random start
     e0 = dq.energy(X0)
     X1, d1 = dq.anneal(R, 50, seed=5)
