@@ -45,7 +45,7 @@ struct KronArgs {
 // rows: the tile's first row inside the core's block (krow0), valid while < P; v0 = state index of row krow0.
 template <bool ENERGY, int WN>
 __device__ inline void kron_epilogue(const KronArgs& p, v16i (&acc)[2][WN], int64_t v0, int krow0, int P, int r0, int wm,
-                                     int wn, int lane) {
+                                     int wn, int lane, const uint16_t* sbits) {
     // accumulator element k of lane l: row (k & 3) + 8 * (k >> 2) + 4 * (l >> 5), column l & 31
     const int h = lane >> 5;
     if constexpr (!ENERGY) {
@@ -71,18 +71,26 @@ __device__ inline void kron_epilogue(const KronArgs& p, v16i (&acc)[2][WN], int6
                 for (int g = 0; g < 4; ++g) {
                     const int i = wm * 64 + a * 32 + 8 * g + 4 * h;  // four consecutive rows; P is a multiple of 32
                     if (krow0 + i < P) {
-                        const uint32_t x4 = *reinterpret_cast<const uint32_t*>(p.Xt + (size_t)col * p.m.Npad + v0 + i);
+                        // the states of rows i..i+3 of this replica: four bits of the tile's own piece of the B operand
+                        const uint32_t x4 = (uint32_t)sbits[(col - r0) * (kTile / 16) + (i >> 4)] >> (i & 15);
                         const int4 lin = *reinterpret_cast<const int4*>(p.m.linear + v0 + i);
                         const int l4[4] = {lin.x, lin.y, lin.z, lin.w};
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
-                            if ((x4 >> (8 * j)) & 1u) s += 2 * l4[j] + acc[a][b][4 * g + j];
+                            if ((x4 >> j) & 1u) s += 2 * l4[j] + acc[a][b][4 * g + j];
                     }
                 }
             s += __shfl_xor(s, 32, 64);
             if (h == 0) atomicAdd(&p.out[col], s);
         }
     }
+}
+
+// bit k of the result = lowest bit of byte k of the 16 bytes
+__device__ inline uint16_t low_bits16(const uint4& v) {
+    // byte i's low bit lands on bit 24 + i (8 i + 24 - 7 i); the other partial products stay below bit 24
+    auto nib = [](uint32_t x) -> uint32_t { return ((x & 0x01010101u) * 0x01020408u) >> 24; };
+    return (uint16_t)(nib(v.x) | nib(v.y) << 4 | nib(v.z) << 8 | nib(v.w) << 12);
 }
 
 // WN = MFMA tiles per wave along the replica axis: 2 (128 replicas per workgroup) or 4 (256).  With 4, a
@@ -92,6 +100,9 @@ __global__ __launch_bounds__(256, 2) void k_qubo_kron(KronArgs p) {
     constexpr int kCols = 64 * WN;  // replicas per workgroup
     __shared__ __align__(16) int8_t sA[kTile * kPitch];
     __shared__ __align__(16) int8_t sB[kCols * kPitch];
+    // energy: bit k of sbits[replica][piece] = state of the tile's row piece * 16 + k (the rows of the tile are a
+    // 128-byte piece of the B operand: it is caught on its way through the staging registers)
+    __shared__ uint16_t sbits[ENERGY ? kCols * (kTile / 16) : 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int tile = blockIdx.y, coltile = blockIdx.x;  // the replica tiles of one row tile run side by side
@@ -162,6 +173,21 @@ __global__ __launch_bounds__(256, 2) void k_qubo_kron(KronArgs p) {
                 *reinterpret_cast<uint4*>(wb + 192 * kPitch) = rb6;
                 *reinterpret_cast<uint4*>(wb + 224 * kPitch) = rb7;
             }
+            if constexpr (ENERGY) {
+                if (k0 == krow0) {  // this K tile holds the states of the tile's own rows
+                    uint16_t* sb = sbits + srow * (kTile / 16) + spiece;
+                    sb[0] = low_bits16(rb0);
+                    sb[32 * (kTile / 16)] = low_bits16(rb1);
+                    sb[64 * (kTile / 16)] = low_bits16(rb2);
+                    sb[96 * (kTile / 16)] = low_bits16(rb3);
+                    if constexpr (WN == 4) {
+                        sb[128 * (kTile / 16)] = low_bits16(rb4);
+                        sb[160 * (kTile / 16)] = low_bits16(rb5);
+                        sb[192 * (kTile / 16)] = low_bits16(rb6);
+                        sb[224 * (kTile / 16)] = low_bits16(rb7);
+                    }
+                }
+            }
         }
         __syncthreads();
         if (k0 + kBK < P) QP_LOAD_TILE(k0 + kBK);
@@ -184,7 +210,134 @@ __global__ __launch_bounds__(256, 2) void k_qubo_kron(KronArgs p) {
         }
     }
 #undef QP_LOAD_TILE
-    kron_epilogue<ENERGY, WN>(p, acc, vcore + krow0, krow0, P, r0, wm, wn, lane);
+    kron_epilogue<ENERGY, WN>(p, acc, vcore + krow0, krow0, P, r0, wm, wn, lane, sbits);
+}
+
+// The same contraction with the states resident: workgroup = (slice, core, 128 replicas).  Its piece of the B
+// operand (128 replicas x P bytes) is read from device memory once and stays in LDS while the workgroup walks
+// all 128-row tiles of `same` (which stream through LDS from the cache, 128 x 128 bytes at a time).  With one
+// workgroup per row tile, as in k_qubo_kron, the states are read once per row tile, and that traffic is
+// what bounds the kernel.  Row pitch of the resident states: P rounded up to 128, plus 16 (an odd number of
+// 16-byte slots: conflict-free ds_read_b128).  Used when that fits LDS beside the `same` tile.
+template <bool ENERGY>
+__global__ __launch_bounds__(256, 2) void k_qubo_kron_resident(KronArgs p) {
+    constexpr int WN = 2;
+    constexpr int kCols = 64 * WN;
+    extern __shared__ __align__(16) int8_t smem_res[];
+    __shared__ __align__(16) int8_t sA[kTile * kPitch];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int work = blockIdx.y, coltile = blockIdx.x;
+    const int t = work / p.m.C, j = work - t * p.m.C;  // work item = (slice, core)
+    const int P = p.m.pitch[t];
+    const int Pp = (P + kTile - 1) / kTile * kTile;
+    const int MT = Pp / kTile;
+    const int bpitch = Pp + 16;
+    const int64_t vcore = p.m.off[t] + (int64_t)j * P;
+    const int r0 = coltile * kCols;
+    int8_t* sB = smem_res;
+
+    // the states of this core for the workgroup's replicas -> LDS (zeros past the core's P bytes)
+    const int srow = tid >> 3, spiece = tid & 7;
+    const int8_t* Bb = p.Xt + (size_t)r0 * p.m.Npad + vcore;
+    for (int k0 = 0; k0 < Pp; k0 += kBK) {
+        const bool in_ = k0 + spiece * 16 < P;
+#pragma unroll
+        for (int i = 0; i < kCols / 32; ++i) {
+            const int row = srow + 32 * i;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (in_) v = *reinterpret_cast<const uint4*>(Bb + (size_t)row * p.m.Npad + k0 + spiece * 16);
+            *reinterpret_cast<uint4*>(sB + row * bpitch + k0 + spiece * 16) = v;
+        }
+    }
+    const int8_t* Abase = p.m.same + p.m.same_off[t];
+    for (int mt = 0; mt < MT; ++mt) {
+        const int krow0 = mt * kTile;
+        v16i acc[2][WN];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < WN; ++b)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc[a][b][k] = 0;
+        const int8_t* Ab = Abase + (size_t)krow0 * Pp + (size_t)srow * Pp + spiece * 16;
+        uint4 ra0 = *reinterpret_cast<const uint4*>(Ab);
+        uint4 ra1 = *reinterpret_cast<const uint4*>(Ab + (size_t)32 * Pp);
+        uint4 ra2 = *reinterpret_cast<const uint4*>(Ab + (size_t)64 * Pp);
+        uint4 ra3 = *reinterpret_cast<const uint4*>(Ab + (size_t)96 * Pp);
+        for (int k0 = 0; k0 < P; k0 += kBK) {
+            __syncthreads();  // the previous tile of `same` has been consumed (first pass: the states are in place)
+            {
+                int8_t* wa = sA + srow * kPitch + spiece * 16;
+                *reinterpret_cast<uint4*>(wa) = ra0;
+                *reinterpret_cast<uint4*>(wa + 32 * kPitch) = ra1;
+                *reinterpret_cast<uint4*>(wa + 64 * kPitch) = ra2;
+                *reinterpret_cast<uint4*>(wa + 96 * kPitch) = ra3;
+            }
+            __syncthreads();
+            if (k0 + kBK < P) {
+                ra0 = *reinterpret_cast<const uint4*>(Ab + k0 + kBK);
+                ra1 = *reinterpret_cast<const uint4*>(Ab + (size_t)32 * Pp + k0 + kBK);
+                ra2 = *reinterpret_cast<const uint4*>(Ab + (size_t)64 * Pp + k0 + kBK);
+                ra3 = *reinterpret_cast<const uint4*>(Ab + (size_t)96 * Pp + k0 + kBK);
+            }
+#pragma unroll
+            for (int kk = 0; kk < kBK / 32; ++kk) {
+                if (k0 + kk * 32 >= P) break;
+                v4i fa[2], fb[WN];
+                const int koff = kk * 32 + (lane >> 5) * 16;
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+                    fa[a] = *reinterpret_cast<const v4i*>(sA + (wm * 64 + a * 32 + (lane & 31)) * kPitch + koff);
+#pragma unroll
+                for (int b = 0; b < WN; ++b)
+                    fb[b] = *reinterpret_cast<const v4i*>(sB + (wn * 32 * WN + b * 32 + (lane & 31)) * bpitch + k0 + koff);
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < WN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[a], fb[b], acc[a][b], 0, 0, 0);
+            }
+        }
+        // epilogue of this row tile; the states of its rows are bytes krow0 + i of the resident piece
+        const int h = lane >> 5;
+        const int64_t v0 = vcore + krow0;
+        if constexpr (!ENERGY) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < WN; ++b) {
+                    const int col = r0 + wn * 32 * WN + b * 32 + (lane & 31);
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const int i = wm * 64 + a * 32 + (k & 3) + 8 * (k >> 2) + 4 * h;
+                        if (krow0 + i < P) p.out[(size_t)(v0 + i) * p.R + col] = acc[a][b][k];
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int b = 0; b < WN; ++b) {
+                const int lcol = wn * 32 * WN + b * 32 + (lane & 31);
+                int s = 0;
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int i = wm * 64 + a * 32 + 8 * g + 4 * h;  // four consecutive rows; P is a multiple of 32
+                        if (krow0 + i < P) {
+                            const uint32_t x4 = *reinterpret_cast<const uint32_t*>(sB + lcol * bpitch + krow0 + i);
+                            const int4 lin = *reinterpret_cast<const int4*>(p.m.linear + v0 + i);
+                            const int l4[4] = {lin.x, lin.y, lin.z, lin.w};
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                if ((x4 >> (8 * q)) & 1u) s += 2 * l4[q] + acc[a][b][4 * g + q];
+                        }
+                    }
+                s += __shfl_xor(s, 32, 64);
+                if (h == 0) atomicAdd(&p.out[r0 + lcol], s);
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -255,25 +408,38 @@ __device__ inline int hop_pairs(uint32_t a, uint32_t b, const int32_t* h, int C)
 // The terms of sum_v x_v F_v that the `same` matrix does not hold, from the masks: a qubit on p cores adds
 // 8 p (p - 1) (same qubit, two cores), a qubit present in the next slice as well adds twice (once from each
 // end) 10 * hops over all pairs (core now, core then).  Thread = replica; block y = slice.
+constexpr int kExtraK = 32;  // qubits per block
+
 __global__ __launch_bounds__(256) void k_qubo_extra_energy(KronArgs p) {
     __shared__ int32_t h[32 * 32];
     const int t = blockIdx.y, C = p.m.C;
+    const int n = p.m.n[t];
+    const int kb = blockIdx.z * kExtraK;
+    if (kb >= n) return;
     for (int i = threadIdx.x; i < C * C; i += 256) h[i] = p.m.hops10[i];
     __syncthreads();
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r >= p.R) return;
-    const int n = p.m.n[t];
     const uint32_t* mk = p.masks + (size_t)t * p.m.nmax * p.R + r;
     const uint32_t* mk_next = mk + (size_t)p.m.nmax * p.R;
     const int32_t* nxt = p.m.next + (size_t)t * p.m.nmax;
     const bool has_next = t + 1 < p.m.T;
     int e = 0;
-    for (int k = 0; k < n; ++k) {
-        const uint32_t m = mk[(size_t)k * p.R];
-        const int pc = __popc(m);
-        e += 8 * pc * (pc - 1);
-        const int k2 = has_next ? nxt[k] : -1;
-        if (k2 >= 0 && m) e += 2 * hop_pairs(m, mk_next[(size_t)k2 * p.R], h, C);
+    for (int k0 = kb; k0 < min(n, kb + kExtraK); k0 += 8) {
+        uint32_t m[8], m2[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {  // eight qubits' masks (and their next-slice masks) in flight
+            const int k = min(k0 + i, n - 1);
+            const int k2 = has_next ? nxt[k] : -1;
+            m[i] = k0 + i < n ? mk[(size_t)k * p.R] : 0u;
+            m2[i] = k2 >= 0 ? mk_next[(size_t)k2 * p.R] : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int pc = __popc(m[i]);
+            e += 8 * pc * (pc - 1);
+            if (m[i] && m2[i]) e += 2 * hop_pairs(m[i], m2[i], h, C);
+        }
     }
     atomicAdd(&p.out[r], e);
 }
@@ -544,6 +710,26 @@ KronArgs kron_args(const QpQuboKron* m, const int8_t* Xt, int32_t R, int32_t* ou
     return a;
 }
 
+// The contraction: states resident in LDS when the widest slice's piece fits twice per CU, else a workgroup
+// per row tile.  max_pitch = largest pitch[t] (the host side knows it: nmax + cap rounded up to 32).
+template <bool ENERGY>
+int launch_kron(const KronArgs& a, hipStream_t stream) {
+    const int P = (a.m.nmax + a.m.cap + 31) / 32 * 32;
+    const int Pp = (P + kTile - 1) / kTile * kTile;
+    const size_t res = (size_t)128 * (Pp + 16);
+    if (res + (size_t)kTile * kPitch <= 78 * 1024) {
+        auto kern = k_qubo_kron_resident<ENERGY>;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)res));
+        kern<<<dim3(a.R / 128, a.m.T * a.m.C), 256, res, stream>>>(a);
+    } else if (a.R % 256 == 0) {
+        k_qubo_kron<ENERGY, 4><<<dim3(a.R / 256, a.m.n_tiles), 256, 0, stream>>>(a);
+    } else {
+        k_qubo_kron<ENERGY, 2><<<dim3(a.R / 128, a.m.n_tiles), 256, 0, stream>>>(a);
+    }
+    HIP_TRY(hipGetLastError());
+    return QP_OK;
+}
+
 int launch_bits(const KronArgs& a, hipStream_t stream) {
     const size_t lds = (size_t)kBitsR * (a.m.C * kBitsK + 4);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_qubo_bits), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -566,9 +752,7 @@ extern "C" int qp_qubo_fields_i32(const QpQuboKron* m, const int8_t* Xt, int32_t
     const KronArgs a = kron_args(m, Xt, R, F, ws);
     HIP_TRY(hipMemsetAsync(F, 0, (size_t)m->Npad * R * sizeof(int32_t), stream));  // padding rows are never written
     if (int rc = launch_bits(a, stream)) return rc;
-    if (R % 256 == 0) k_qubo_kron<false, 4><<<dim3(R / 256, m->n_tiles), 256, 0, stream>>>(a);
-    else k_qubo_kron<false, 2><<<dim3(R / 128, m->n_tiles), 256, 0, stream>>>(a);
-    HIP_TRY(hipGetLastError());
+    if (int rc = launch_kron<false>(a, stream)) return rc;
     k_qubo_extra_fields<<<dim3((R + 255) / 256, m->T, (m->nmax + 15) / 16), 256, 0, stream>>>(a);
     HIP_TRY(hipGetLastError());
     return QP_OK;
@@ -581,10 +765,8 @@ extern "C" int qp_qubo_energy_i32(const QpQuboKron* m, const int8_t* Xt, int32_t
     const KronArgs a = kron_args(m, Xt, R, energy, ws);
     HIP_TRY(hipMemsetAsync(energy, 0, (size_t)R * sizeof(int32_t), stream));
     if (int rc = launch_bits(a, stream)) return rc;
-    if (R % 256 == 0) k_qubo_kron<true, 4><<<dim3(R / 256, m->n_tiles), 256, 0, stream>>>(a);
-    else k_qubo_kron<true, 2><<<dim3(R / 128, m->n_tiles), 256, 0, stream>>>(a);
-    HIP_TRY(hipGetLastError());
-    k_qubo_extra_energy<<<dim3((R + 255) / 256, m->T), 256, 0, stream>>>(a);
+    if (int rc = launch_kron<true>(a, stream)) return rc;
+    k_qubo_extra_energy<<<dim3((R + 255) / 256, m->T, (m->nmax + kExtraK - 1) / kExtraK), 256, 0, stream>>>(a);
     HIP_TRY(hipGetLastError());
     k_qubo_finish<<<(R + 255) / 256, 256, 0, stream>>>(energy, R, m->constant);
     HIP_TRY(hipGetLastError());
