@@ -646,12 +646,8 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_pairs(V3Args p) {
                     av[c] = strip[g >> 16];
                 }
                 const uint32_t c0 = cur.x & keep[0], c1 = cur.y & keep[1], c2 = cur.z & keep[2], c3 = cur.w & keep[3];
-                if (row >= 2) {  // movement is charged from row 2 on; a dword of qubits that all stayed is skipped
-                    if (c0 != p0) count4(p0, c0);
-                    if (c1 != p1) count4(p1, c1);
-                    if (c2 != p2) count4(p2, c2);
-                    if (c3 != p3) count4(p3, c3);
-                }
+                // the gates first: their counts hang on the gathers just issued, and LDS operations complete in
+                // order, so whatever is issued between a gather and its use is waited for as well
                 static_assert(kRowEdgeChunks == 4, "the first four gate chunks of a row are counted two to a register");
                 count_gates2(au[0] | au[1] << 16, av[0] | av[1] << 16);
                 count_gates2(au[2] | au[3] << 16, av[2] | av[3] << 16);
@@ -659,6 +655,12 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_pairs(V3Args p) {
                     const uint32_t g = sched_lane[s0 + c * kWave];
                     const uint32_t u = strip[g & 0xFFFFu], v = strip[g >> 16];
                     count_gates2(u, v);  // the upper halves are the pair (0, 0): a diagonal slot
+                }
+                if (row >= 2) {  // movement is charged from row 2 on; a dword of qubits that all stayed is skipped
+                    if (c0 != p0) count4(p0, c0);
+                    if (c1 != p1) count4(p1, c1);
+                    if (c2 != p2) count4(p2, c2);
+                    if (c3 != p3) count4(p3, c3);
                 }
                 p0 = c0;
                 p1 = c1;
