@@ -14,6 +14,7 @@ import torch  # noqa: E402
 
 import test_gpu_cost as TC  # noqa: E402
 import test_gpu_placers as TP  # noqa: E402
+import test_gpu_qubo as TQ  # noqa: E402
 from quantum_simulator_amd import engine  # noqa: E402
 
 
@@ -71,6 +72,42 @@ def cost_matrix_case(gpu, Q, T, C, cap, kind, seed):
         assert got.tobytes() == want.tobytes(), (kind, b, tt)
 
 
+def hqa_batch_case(Q, T, nx, ny, topo, cap, kind, B, seed):
+    """A native HQA / TRHQA placement batch (qp_hqa_place_batch) from shuffled starting assignments against the
+    sequential restatement, row for row; with S > 1 damaged copies of the network, one per instance."""
+    import random
+    from oracle import placer_oracle as O
+    from quantum_simulator_amd import layered_circuit
+    from quantum_simulator_amd.multicore import multicore
+    from quantum_simulator_amd.placers import PLACERS
+    rng = np.random.default_rng(seed)
+    circ = layered_circuit(Q, T, float(rng.choice([0.3, 0.6, 0.9])), seed=seed % 100000)
+    random.seed(seed)
+    wr = (2.0, 2.0) if seed % 3 == 0 else (1.0, 3.0)
+    arch = multicore(nx, ny, ncp_qubits=cap, edge_weight_range=wr, network_type=topo)
+    placer = PLACERS[kind.upper()]()
+    ctx = placer._context(circ, arch)
+    C = ctx.arch.C
+    if Q > C * cap or cap < 2:
+        return
+    slots = np.repeat(np.arange(C), cap)
+    inits = np.stack([rng.permutation(slots)[:Q] for _ in range(B)]).astype(np.uint8)
+    ir = ctx.ir
+    if seed % 2:
+        got = placer.place_batch(circ, arch, initial=inits, threads=int(rng.integers(1, 5)))
+        tables = [ctx.arch.D] * B
+    else:  # every instance on its own damaged network
+        W = np.tile(np.asarray(ctx.arch.w, np.float64), (B, 1))
+        W[rng.random(W.shape) < 0.1] = np.inf
+        W[0] = ctx.arch.w
+        tabs = engine.apsp_batch(C, ctx.arch.eu, ctx.arch.ev, W)
+        got = placer.place_batch(circ, arch, initial=inits, tables=tabs, tab_index=np.arange(B, dtype=np.int32))
+        tables = list(tabs)
+    for b in range(B):
+        want = O.place_hqa_family(ir.slices, ir.gate_q, ir.gate_mr, Q, C, cap, tables[b].tolist(), kind, init=inits[b].tolist())
+        assert (got[b] == np.array(want, np.uint8)).all(), (kind, b, np.argwhere(got[b] != np.array(want, np.uint8))[:4])
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
@@ -87,7 +124,17 @@ def main():
         return [pick(2, 80), pick(81, 512), pick(513, 1024), pick(1025, 1600)][pick(0, 3)]
 
     def draw():
-        kind = pick(0, 6)
+        kind = pick(0, 9)
+        if kind == 9:
+            C = [4, 9, 16, 25][pick(0, 3)]
+            return "qubo_energy_fields", TQ.test_energy_and_fields_exact, ((torch, dev), pick(8, 70), pick(1, 7), C, pick(2, 12), pick(0, 1 << 20))
+        if kind == 8:
+            topo, nx, ny = [("mesh", pick(2, 8), pick(1, 8)), ("torus", pick(3, 8), pick(3, 8)), ("line", pick(2, 40), 1),
+                            ("star", pick(3, 30), 1), ("all_to_all", pick(2, 4), pick(1, 4))][pick(0, 4)]
+            return "hqa_place_batch", hqa_batch_case, (pick(2, 120), pick(2, 25), nx, ny, topo, pick(2, 6), ["hqa", "trhqa"][pick(0, 1)],
+                                                       pick(1, 7), pick(0, 1 << 30))
+        if kind == 7:
+            return "cost_v3_multi", TP.test_cost_v3_with_a_table_per_partition, (wide_q(), pick(1, 40), pick(2, 256), pick(1, 6))
         if kind == 6:  # rows longer than 1 KB: one or four 16-byte pieces per thread, one or several chunks of rows
             Q = pick(16385, 24000) if pick(0, 5) == 0 else pick(1025, 6000)
             T = pick(1, max(1, min(600, 1200000 // Q)))
