@@ -679,20 +679,21 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_pairs(V3Args p) {
                 if (g0 + k < w1) do_row(g0 + k, ring[k], gring[k], sring[k], ering[k], false);
         }
         __syncthreads();
-        // table entries are loaded whether or not the pair occurred (coalesced, cache-resident), eight at a
+        // table entries are loaded whether or not the pair occurred (coalesced, cache-resident), sixteen at a
         // time, so the loop is not a chain of load latencies; an unused entry may be infinite: select, not multiply
         double acc = 0.0;
-        static_assert(kPairSlots % (8 * kV3Threads) == 0, "whole batches of eight slots per thread");
-        for (int k0 = threadIdx.x; k0 < kPairSlots; k0 += 8 * kV3Threads) {
-            double d[8];
-            uint32_t n[8];
+        constexpr int kBatch = 16;  // slots per thread whose table entries are in flight together
+        static_assert(kPairSlots % (kBatch * kV3Threads) == 0, "whole batches of slots per thread");
+        for (int k0 = threadIdx.x; k0 < kPairSlots; k0 += kBatch * kV3Threads) {
+            double d[kBatch];
+            uint32_t n[kBatch];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < kBatch; ++j) {
                 d[j] = fold[k0 + j * kV3Threads];
                 n[j] = cnt[k0 + j * kV3Threads];
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < kBatch; ++j) {
                 if (n[j]) {
                     cnt[k0 + j * kV3Threads] = 0;
                     acc += (double)n[j] * d[j];
