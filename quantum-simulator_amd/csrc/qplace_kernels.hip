@@ -486,6 +486,222 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_row(V3Args p) {
     }
 }
 
+// Rows of 513..1024 bytes with the table in LDS at pitch 256, four partitions at a time.  The gates of slice t
+// are the same for every partition, so a wave takes row t of four consecutive partitions in one step and parks
+// them interleaved: strip word q = the cores of qubit q in the four partitions.  One ds_read_b32 then fetches a
+// gate endpoint for all four (two gathers per row and partition instead of eight), and a (word of first
+// endpoints, word of second endpoints) pair feeds the same packed look-ups as a (previous, current) pair of
+// movement words, one partition per byte lane.  The LDS instruction count per row drops from 29 to 23, and
+// that count is what bounds the table kernels.  Eight waves per workgroup: 8 x 4 KB of strips beside a 128 KB
+// table fill the CU's LDS exactly.
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+
+// The two table entries (2- or 8-byte elements, table at LDS address `base`) whose indices are the 16-bit halves
+// of x: one v_mad_u32_u16 per entry forms the address from a half without unpacking it first.
+template <typename E>
+__device__ inline void entries_at_halves(uint32_t x, uint32_t base, E& e0, E& e1) {
+    typedef __attribute__((address_space(3))) const E lds_e;
+    uint32_t a0, a1;
+    if constexpr (sizeof(E) == 2) {
+        asm("v_mad_u32_u16 %0, %1, 2, %2 op_sel:[0,0,0,0]" : "=v"(a0) : "v"(x), "s"(base));
+        asm("v_mad_u32_u16 %0, %1, 2, %2 op_sel:[1,0,0,0]" : "=v"(a1) : "v"(x), "s"(base));
+    } else {
+        static_assert(sizeof(E) == 8, "2- or 8-byte table entries");
+        asm("v_mad_u32_u16 %0, %1, 8, %2 op_sel:[0,0,0,0]" : "=v"(a0) : "v"(x), "s"(base));
+        asm("v_mad_u32_u16 %0, %1, 8, %2 op_sel:[1,0,0,0]" : "=v"(a1) : "v"(x), "s"(base));
+    }
+    e0 = *(lds_e*)(uintptr_t)a0;
+    e1 = *(lds_e*)(uintptr_t)a1;
+}
+
+constexpr int kRow4Waves = 8;
+constexpr int kRow4Threads = kRow4Waves * kWave;
+constexpr int kRow4Strip = 4096;
+
+template <int KIND, int AHEAD>
+__global__ __launch_bounds__(kRow4Threads) void k_cost_v3_row4(V3Args p) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    using E = typename Tab<KIND>::elem;
+    using Acc = typename Tab<KIND>::acc;
+    static_assert(kRowEdgeChunks == 4, "four gate chunks per row are prefetched");
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const uint32_t tab_off = stage_table_pitch256<E>(smem, p.table, p.C);
+    const uint32_t tbase = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_u8*)smem);  // the table's LDS address
+    uint32_t* strip = reinterpret_cast<uint32_t*>(smem + tab_off + (size_t)wave * kRow4Strip);  // [qubit] -> 4 cores
+    const int ldq = p.ldq;
+    const bool lane_on = lane * 16 < ldq;
+    const int lane16 = lane_on ? lane * 16 : 0;
+    const int nvalid_row = min(16, max(0, p.Q - lane * 16));
+    uint32_t keep[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const int nb = min(4, max(0, nvalid_row - 4 * w));
+        keep[w] = nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u);
+    }
+    const uint32_t* sched_lane = p.edges_sched + lane;
+    const int64_t ngroups = (p.B + 3) / 4;
+    // A lane parks its 16 qubits as four 16-byte writes into its own 64 bytes of the strip.  Eight lanes make one
+    // LDS pass; with every lane writing the same quarter they would meet in 8 of the 32 banks, so lane pairs
+    // permute their quarters: qubit q sits at word q ^ (((q >> 5) & 3) << 2).  Both qubits of a packed gate word
+    // are mapped at once, and one v_mad_u32_u16 per endpoint turns a half into the LDS address of its strip word.
+    const int quarter_x = (lane >> 1) & 3;
+    const uint32_t sbase = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_u8*)smem + tab_off + (uint32_t)wave * kRow4Strip);
+    auto endpoints = [&](uint32_t g, uint32_t& u4, uint32_t& v4) {
+        const uint32_t x = g ^ ((g >> 3) & 0x000C000Cu);
+        uint32_t a0, a1;
+        asm("v_mad_u32_u16 %0, %1, 4, %2 op_sel:[0,0,0,0]" : "=v"(a0) : "v"(x), "s"(sbase));
+        asm("v_mad_u32_u16 %0, %1, 4, %2 op_sel:[1,0,0,0]" : "=v"(a1) : "v"(x), "s"(sbase));
+        u4 = *(lds_u32*)(uintptr_t)a0;
+        v4 = *(lds_u32*)(uintptr_t)a1;
+    };
+    for (int64_t it = (int64_t)blockIdx.x * kRow4Waves + wave; it < p.nitems; it += (int64_t)gridDim.x * kRow4Waves) {  // items = chunks x groups
+        const int chunk = (int)(it / ngroups);
+        const int64_t b0 = (it - (int64_t)chunk * ngroups) * 4;
+        const int r0 = chunk * p.rows_per_item;
+        const int r1 = min(p.T, r0 + p.rows_per_item);
+        const uint8_t* base[4];  // a group that runs past B repeats the last partition and drops the copies
+#pragma unroll
+        for (int g = 0; g < 4; ++g) base[g] = p.A + (size_t)min(b0 + g, p.B - 1) * p.Tp * ldq + lane16;
+        Acc acc[4] = {0, 0, 0, 0};
+
+        auto fetch_row = [&](int row, int g) -> uint4 { return load_row16(base[g] + (size_t)min(row, r1 - 1) * ldq); };
+        auto fetch_gate = [&](int row, int c) -> uint32_t { return sched_lane[p.sptr[min(row, r1 - 1)] + c * kWave]; };
+        // one look-up per partition: the byte lanes of (from, to) index the table as from << 8 | to
+        auto look4 = [&](uint32_t from, uint32_t to) {
+            E e0, e1, e2, e3;
+            entries_at_halves<E>(__builtin_amdgcn_perm(from, to, 0x05010400u), tbase, e0, e1);
+            entries_at_halves<E>(__builtin_amdgcn_perm(from, to, 0x07030602u), tbase, e2, e3);
+            acc[0] += (Acc)e0;
+            acc[1] += (Acc)e1;
+            acc[2] += (Acc)e2;
+            acc[3] += (Acc)e3;
+        };
+        // the four look-ups of one partition's (previous, current) word
+        auto four = [&](int g, uint32_t pf, uint32_t cf) {
+            E e0, e1, e2, e3;
+            entries_at_halves<E>(__builtin_amdgcn_perm(pf, cf, 0x05010400u), tbase, e0, e1);
+            entries_at_halves<E>(__builtin_amdgcn_perm(pf, cf, 0x07030602u), tbase, e2, e3);
+            acc[g] += ((Acc)e0 + (Acc)e1) + ((Acc)e2 + (Acc)e3);
+        };
+
+        uint32_t prev[4][4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (r0 >= 1) v = fetch_row(r0 - 1, g);
+            prev[g][0] = v.x & keep[0];
+            prev[g][1] = v.y & keep[1];
+            prev[g][2] = v.z & keep[2];
+            prev[g][3] = v.w & keep[3];
+        }
+        uint4 ring[AHEAD][4];
+        uint32_t gring[AHEAD][kRowEdgeChunks];
+#pragma unroll
+        for (int k = 0; k < AHEAD; ++k) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) ring[k][g] = fetch_row(r0 + k, g);
+#pragma unroll
+            for (int c = 0; c < kRowEdgeChunks; ++c) gring[k][c] = fetch_gate(r0 + k, c);
+        }
+        // interleave: word w of the four partitions -> four strip words (one per qubit), 4 x 4 byte transposes
+        auto park = [&](const uint32_t (&x)[4][4]) {
+            if (lane_on) {
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const uint32_t t01a = __builtin_amdgcn_perm(x[1][w], x[0][w], 0x05010400u);  // a0 b0 a1 b1
+                    const uint32_t t01b = __builtin_amdgcn_perm(x[1][w], x[0][w], 0x07030602u);  // a2 b2 a3 b3
+                    const uint32_t t23a = __builtin_amdgcn_perm(x[3][w], x[2][w], 0x05010400u);  // c0 d0 c1 d1
+                    const uint32_t t23b = __builtin_amdgcn_perm(x[3][w], x[2][w], 0x07030602u);
+                    uint4 o;
+                    o.x = __builtin_amdgcn_perm(t23a, t01a, 0x05040100u);  // a0 b0 c0 d0
+                    o.y = __builtin_amdgcn_perm(t23a, t01a, 0x07060302u);  // a1 b1 c1 d1
+                    o.z = __builtin_amdgcn_perm(t23b, t01b, 0x05040100u);
+                    o.w = __builtin_amdgcn_perm(t23b, t01b, 0x07060302u);
+                    *reinterpret_cast<uint4*>(strip + lane * 16 + 4 * (w ^ quarter_x)) = o;
+                }
+            }
+        };
+        // endpoint words of the first chunks of a row's gates from the strip that holds that row (a chunk the row
+        // lacks: qubit 0 with itself, distance zero)
+        auto gather = [&](int row, const uint32_t (&gates)[kRowEdgeChunks], uint32_t (&U)[kRowEdgeChunks], uint32_t (&V)[kRowEdgeChunks]) {
+            const int rr = min(row, r1 - 1);
+            const int nch = (p.sptr[rr + 1] - p.sptr[rr]) / kWave;
+#pragma unroll
+            for (int c = 0; c < kRowEdgeChunks; ++c) {
+                endpoints(c < nch ? gates[c] : 0u, U[c], V[c]);
+            }
+        };
+        auto masked = [&](const uint4 (&r)[4], uint32_t (&x)[4][4]) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                x[g][0] = r[g].x & keep[0];
+                x[g][1] = r[g].y & keep[1];
+                x[g][2] = r[g].z & keep[2];
+                x[g][3] = r[g].w & keep[3];
+            }
+        };
+        // The strip write and the gathers of row t + 1 are issued before the table look-ups of row t, whose
+        // addresses were gathered one step earlier: one LDS round trip per step in the dependency chain, not two.
+        uint32_t cur[4][4], U[kRowEdgeChunks], V[kRowEdgeChunks];
+        masked(ring[0], cur);
+        park(cur);
+        gather(r0, gring[0], U, V);
+        for (int g0 = r0; g0 < r1; g0 += AHEAD) {
+#pragma unroll
+            for (int k = 0; k < AHEAD; ++k) {
+                const int row = g0 + k;
+                if (row >= r1) break;
+                const int kn = (k + 1) % AHEAD;  // slot of row + 1 (slot 0 was refilled earlier in this pass)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) ring[k][g] = fetch_row(row + AHEAD, g);
+#pragma unroll
+                for (int c = 0; c < kRowEdgeChunks; ++c) gring[k][c] = fetch_gate(row + AHEAD, c);
+                // gates beyond the prefetched chunks (rare) while the strip still holds this row
+                const int s0 = p.sptr[row];
+                const int nch = (p.sptr[row + 1] - s0) / kWave;
+                for (int c = kRowEdgeChunks; c < nch; ++c) {
+                    const uint32_t g = sched_lane[s0 + c * kWave];
+                    uint32_t u4, v4;
+                    endpoints(g, u4, v4);
+                    look4(u4, v4);
+                }
+                uint32_t nxt[4][4], Un[kRowEdgeChunks], Vn[kRowEdgeChunks];
+                masked(ring[kn], nxt);
+                park(nxt);
+                gather(row + 1, gring[kn], Un, Vn);
+                if (row >= 2) {  // movement is charged from row 2 on
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int w = 0; w < 4; ++w)
+                            if (cur[g][w] != prev[g][w]) four(g, prev[g][w], cur[g][w]);
+                }
+#pragma unroll
+                for (int c = 0; c < kRowEdgeChunks; ++c) look4(U[c], V[c]);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        prev[g][w] = cur[g][w];
+                        cur[g][w] = nxt[g][w];
+                    }
+#pragma unroll
+                for (int c = 0; c < kRowEdgeChunks; ++c) {
+                    U[c] = Un[c];
+                    V[c] = Vn[c];
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const double sum = wave_sum(acc[g]);
+            if (lane == 0 && b0 + g < p.B) p.partial[(size_t)chunk * p.B + b0 + g] = sum;
+        }
+    }
+}
+
 // fp64 table too large for LDS (more than about 134 cores), symmetric up to rounding: instead of looking
 // distances up, count how often every unordered pair of cores occurs and multiply by the table once per
 // item.  The counters (one uint32 per unordered pair) fit in LDS where the table does not.  One workgroup =
@@ -518,9 +734,6 @@ __global__ void k_sym_fold(const double* D, int32_t C, double* fold) {
     }
     fold[idx] = (hi < C && lo < hi) ? (D[(size_t)lo * C + hi] + D[(size_t)hi * C + lo]) * 0.5 : 0.0;
 }
-
-typedef __attribute__((address_space(3))) uint8_t lds_u8;
-typedef __attribute__((address_space(3))) uint32_t lds_u32;
 
 // hi << 8 | lo of two (a, b) pairs, folded: k = a << 8 | b and s = b << 8 | a in each 16-bit half
 __device__ inline uint32_t fold_keys(uint32_t k, uint32_t s) {
@@ -1577,6 +1790,27 @@ int slice_cost_v3_impl(const QpCircuit* circ, const QpDTable* dt, const uint8_t*
             k_sum_chunks<<<(unsigned)((B + 255) / 256), 256, 0, stream>>>(p.partial, B, nchunks * passes, out);
             HIP_TRY(hipGetLastError());
             return QP_OK;
+        }
+        if (rowpath && tab256 + (size_t)kRow4Waves * kRow4Strip <= (size_t)kLdsBytes && B >= 64) {
+            // table at pitch 256 beside eight interleaved strips: four partitions per wave step (a last group that
+            // is not full repeats a partition, which is at most 5 % more work from 64 partitions on)
+            V3Args q = p;
+            const int64_t ngroups = (B + 3) / 4;
+            const int64_t want = (int64_t)T * ngroups / ((int64_t)cus * kRow4Waves * 4);
+            q.rows_per_item = (int)std::min<int64_t>(T, std::min<int64_t>(256, std::max<int64_t>(32, want)));
+            const int32_t qchunks = (T + q.rows_per_item - 1) / q.rows_per_item;
+            q.nitems = (int64_t)qchunks * ngroups;
+            if (workspace_bytes >= (size_t)qchunks * B * sizeof(double)) {
+                kern = dt->kind == QP_DT_F64 ? k_cost_v3_row4<QP_DT_F64, kV3Ahead> : k_cost_v3_row4<QP_DT_U16, kV3Ahead>;
+                const size_t lds4 = tab256 + (size_t)kRow4Waves * kRow4Strip;
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
+                const unsigned grid4 = (unsigned)std::min<int64_t>(cus, (q.nitems + kRow4Waves - 1) / kRow4Waves);
+                kern<<<grid4, kRow4Threads, lds4, stream>>>(q);
+                HIP_TRY(hipGetLastError());
+                k_sum_chunks<<<(unsigned)((B + 255) / 256), 256, 0, stream>>>(q.partial, B, qchunks, out);
+                HIP_TRY(hipGetLastError());
+                return QP_OK;
+            }
         }
         if (rowpath) {
             if (dt->kind == QP_DT_F64)

@@ -142,6 +142,41 @@ def test_cost_v3_random(gpu, Q, T, C, B, integer):
         assert _close(got[b], want, integer), (b, got[b], want)
 
 
+GROUPED = [  # Q, T, C, B, integer weights: rows over 512 bytes, table in LDS at pitch 256, 64 partitions or more
+    (1000, 70, 256, 67, True), (1024, 9, 64, 64, False), (600, 41, 40, 130, False), (513, 3, 200, 65, True),
+    (777, 2, 64, 66, False), (1024, 1, 256, 64, True),
+]
+
+
+@pytest.mark.parametrize("Q,T,C,B,integer", GROUPED)
+def test_cost_v3_four_partitions_per_wave(gpu, Q, T, C, B, integer):
+    """From 64 partitions on, long rows with an LDS-resident table are costed four partitions per wave step
+    (one interleaved strip of core ids); B is not always a multiple of four.  Every partition against the
+    vectorised CPU sum (exact for integer tables, 1e-12 otherwise), the first and last few against the
+    sequential oracle."""
+    from oracle.cpu_variants import NumpyCost
+    torch, engine, eng, dev = gpu
+    ir, eu, ev, w, rng = _random_setup(Q, T, C, integer, seed=Q * 11 + T)
+    D = engine.apsp(C, eu, ev, w)
+    dc, dt = engine.DeviceCircuit(ir, dev), engine.DistanceTable(D, dev)
+    assert (dt.kind == engine.QP_DT_U16) == integer
+    A = np.empty((B, ir.T, dc.ldq), np.uint8)
+    A[:, 0] = rng.integers(0, C, size=(B, dc.ldq), dtype=np.uint8)
+    for t in range(1, ir.T):
+        move = rng.random((B, dc.ldq)) < 0.4
+        A[:, t] = np.where(move, rng.integers(0, C, size=(B, dc.ldq), dtype=np.uint8), A[:, t - 1])
+    A[:, :, Q:] = rng.integers(0, 256, size=(B, ir.T, dc.ldq - Q), dtype=np.uint8)  # pad bytes are garbage
+    got = eng.cost_v3(dc, dt, torch.from_numpy(A).to(dev), table="table").cpu().numpy()
+    nc = NumpyCost(ir.slices, ir.gate_q, ir.gate_mr, D)
+    for b in range(B):
+        want = nc.cost(A[b, :, :Q])
+        assert _close(got[b], want, integer), (b, got[b], want)
+    Dl = D.tolist()
+    for b in list(range(3)) + list(range(B - 5, B)):
+        want = O.cost_v3(ir.slices, ir.gate_q, ir.gate_mr, A[b, :, :Q].tolist(), Dl)
+        assert _close(got[b], want, integer), (b, got[b], want)
+
+
 PAIR_SHAPES = [  # Q, T, C, B, chord edges dropped so the graph falls apart, moves per row
     (1024, 40, 256, 3, False, 0.3), (600, 70, 200, 2, False, 0.05), (1021, 5, 140, 2, False, 1.0),
     (700, 33, 256, 2, True, 0.3), (1024, 130, 255, 5, False, 0.02),
