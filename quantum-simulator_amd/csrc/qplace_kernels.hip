@@ -75,6 +75,27 @@ __device__ inline uint32_t stage_table_pitch256(uint8_t* smem, const void* table
     return (uint32_t)(C * 256 * sizeof(E));
 }
 
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+
+// The two table entries (2- or 8-byte elements, table at LDS address `base`) whose indices are the 16-bit halves
+// of x: one v_mad_u32_u16 per entry forms the address from a half without unpacking it first.
+template <typename E>
+__device__ inline void entries_at_halves(uint32_t x, uint32_t base, E& e0, E& e1) {
+    typedef __attribute__((address_space(3))) const E lds_e;
+    uint32_t a0, a1;
+    if constexpr (sizeof(E) == 2) {
+        asm("v_mad_u32_u16 %0, %1, 2, %2 op_sel:[0,0,0,0]" : "=v"(a0) : "v"(x), "s"(base));
+        asm("v_mad_u32_u16 %0, %1, 2, %2 op_sel:[1,0,0,0]" : "=v"(a1) : "v"(x), "s"(base));
+    } else {
+        static_assert(sizeof(E) == 8, "2- or 8-byte table entries");
+        asm("v_mad_u32_u16 %0, %1, 8, %2 op_sel:[0,0,0,0]" : "=v"(a0) : "v"(x), "s"(base));
+        asm("v_mad_u32_u16 %0, %1, 8, %2 op_sel:[1,0,0,0]" : "=v"(a1) : "v"(x), "s"(base));
+    }
+    e0 = *(lds_e*)(uintptr_t)a0;
+    e1 = *(lds_e*)(uintptr_t)a1;
+}
+
 // Where the distance table lives while a cost kernel runs.
 constexpr int kTabLds256 = 0;  // LDS, row pitch 256 entries: index = from << 8 | to
 constexpr int kTabLdsC = 1;    // LDS, row pitch C
@@ -323,6 +344,7 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_row(V3Args p) {
     }
     const int ldq = p.ldq;
     const uint32_t C = (uint32_t)p.C;
+    const uint32_t tbase = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_u8*)smem);  // LDS address of the table
     // a table in device memory is never read past its end, whatever core ids the caller put in A (ids >= C
     // are the caller's error; LDS tables need no guard: out-of-range LDS reads return nothing harmful)
     auto in_table = [&](uint32_t idx) -> uint32_t {
@@ -354,9 +376,10 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_row(V3Args p) {
     };
     auto four = [&](uint32_t pf, uint32_t cf) -> Acc {
         if constexpr (TABMODE == kTabLds256) {
-            const uint32_t lo = __builtin_amdgcn_perm(pf, cf, 0x05010400u);
-            const uint32_t hi = __builtin_amdgcn_perm(pf, cf, 0x07030602u);
-            return (Acc)tab[lo & 0xFFFFu] + (Acc)tab[lo >> 16] + (Acc)tab[hi & 0xFFFFu] + (Acc)tab[hi >> 16];
+            E e0, e1, e2, e3;
+            entries_at_halves<E>(__builtin_amdgcn_perm(pf, cf, 0x05010400u), tbase, e0, e1);
+            entries_at_halves<E>(__builtin_amdgcn_perm(pf, cf, 0x07030602u), tbase, e2, e3);
+            return ((Acc)e0 + (Acc)e1) + ((Acc)e2 + (Acc)e3);
         } else if constexpr (TABMODE == kTabLdsBand) {
             // two 16-bit slots per dword, both clamped onto the zero entry by one packed minimum
             typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
@@ -494,27 +517,6 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_row(V3Args p) {
 // movement words, one partition per byte lane.  The LDS instruction count per row drops from 29 to 23, and
 // that count is what bounds the table kernels.  Eight waves per workgroup: 8 x 4 KB of strips beside a 128 KB
 // table fill the CU's LDS exactly.
-typedef __attribute__((address_space(3))) uint8_t lds_u8;
-typedef __attribute__((address_space(3))) uint32_t lds_u32;
-
-// The two table entries (2- or 8-byte elements, table at LDS address `base`) whose indices are the 16-bit halves
-// of x: one v_mad_u32_u16 per entry forms the address from a half without unpacking it first.
-template <typename E>
-__device__ inline void entries_at_halves(uint32_t x, uint32_t base, E& e0, E& e1) {
-    typedef __attribute__((address_space(3))) const E lds_e;
-    uint32_t a0, a1;
-    if constexpr (sizeof(E) == 2) {
-        asm("v_mad_u32_u16 %0, %1, 2, %2 op_sel:[0,0,0,0]" : "=v"(a0) : "v"(x), "s"(base));
-        asm("v_mad_u32_u16 %0, %1, 2, %2 op_sel:[1,0,0,0]" : "=v"(a1) : "v"(x), "s"(base));
-    } else {
-        static_assert(sizeof(E) == 8, "2- or 8-byte table entries");
-        asm("v_mad_u32_u16 %0, %1, 8, %2 op_sel:[0,0,0,0]" : "=v"(a0) : "v"(x), "s"(base));
-        asm("v_mad_u32_u16 %0, %1, 8, %2 op_sel:[1,0,0,0]" : "=v"(a1) : "v"(x), "s"(base));
-    }
-    e0 = *(lds_e*)(uintptr_t)a0;
-    e1 = *(lds_e*)(uintptr_t)a1;
-}
-
 constexpr int kRow4Waves = 8;
 constexpr int kRow4Threads = kRow4Waves * kWave;
 constexpr int kRow4Strip = 4096;
