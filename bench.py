@@ -9,7 +9,7 @@ seeded random walk instead).  One step = one pass of the cost path over all part
 qp_slice_cost_v3 through the C ABI, inputs resident in HBM.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--weights uniform|integer] [--partitions B]
-                    [--source gtrhqa|walk] [--single] [--no-cpu] [--no-qubo]
+                    [--source gtrhqa|walk] [--single] [--table packed|table] [--no-cpu] [--no-qubo]
 
 For N > 1 launch with torch.distributed.run (one rank per GPU); ranks work on disjoint partitions with
 no collective in the timed region; the final mean/min reduction over ranks (one RCCL all-reduce of a
@@ -17,8 +17,9 @@ few doubles) is done once after it and reported as ``reduce_ms``.
 
 Rank 0 prints one JSON line.  ``roofline`` prices the dominant kernel of the headline variant against
 HBM: algorithmic bytes per launch / mean launch time from HIP events on the launch stream.
-``other_variants`` repeats the measurement with table look-ups forced and with non-integer weights
-(fp64 table); ``gtrhqa_place``, ``cost_matrix`` and ``qubo`` time the other device paths, ``shipped_circuits``
+The headline variant is the reference's default arithmetic (uniform random edge weights, fp64 distance
+table); ``other_variants`` repeats the measurement with integer weights (closed-form grid metric) and with
+the same integer table looked up in LDS, ``roofline_by_weights`` lists the three side by side; ``gtrhqa_place``, ``cost_matrix`` and ``qubo`` time the other device paths, ``shipped_circuits``
 whole placement + cost batches of every placer on two of the reference's own circuits.
 ``cpu_baseline`` times the CPU oracle (a C port of the reference's per_timeslice_cost loop) on a bounded
 sample of the same partitions on every host core, each result checked against the GPU's.
@@ -257,6 +258,9 @@ def main():
                          "own configs draw (multicore.py:159-161); integer (2,2) -> exact uint16 table, on this mesh the "
                          "closed-form grid metric (a special case).  The other one is run too: other_variants")
     ap.add_argument("--single", action="store_true", help="run only the --weights variant")
+    ap.add_argument("--table", choices=["packed", "table"], default="packed",
+                    help="form of the distance table for the headline variant: what the library chooses, or look-ups "
+                         "even where a closed form exists (for profiling the look-up kernel on its own)")
     ap.add_argument("--partitions", type=int, default=4096, help="partitions per GPU")
     ap.add_argument("--qubits", type=int, default=1024)
     ap.add_argument("--slices", type=int, default=1000)
@@ -360,7 +364,8 @@ def main():
         if dt.kind == QP_DT_U16:
             how = ("none: closed-form grid metric (v_sad_u8 on packed core ids), verified against the matrix"
                    if closed else "uint16, LDS-resident")
-            kname = "k_cost_v3_grid_row<false, 4>" if closed else "k_cost_v3_row<1, 0, 4>"  # names as rocprofv3 prints them
+            # names as rocprofv3 prints them; from 64 partitions on, table look-ups take four partitions per wave step
+            kname = "k_cost_v3_grid_row<false, 4>" if closed else ("k_cost_v3_row4<1, 4>" if B >= 64 else "k_cost_v3_row<1, 0, 4>")
         elif C * C * 8 <= 128 * 1024:
             how, kname = "f64, LDS-resident", "k_cost_v3_row<0, 0, 4>"
         elif table == "packed" and dt.symmetric:
@@ -424,7 +429,7 @@ def main():
                 "mean_cost": float(stats[0].item() / stats[1].item()), "min_cost": float(mn.item()),
                 "reduce_ms": reduce_ms, "_D": D, "_kind": dt.kind, "_costs": out.cpu().numpy().copy()}
 
-    primary = run_variant(args.weights)
+    primary = run_variant(args.weights, table=args.table)
     others = []
     if not args.single:
         for weights in (("integer",) if args.weights == "uniform" else ("uniform",)):

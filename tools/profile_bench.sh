@@ -1,7 +1,7 @@
 #!/bin/bash
 # Usage: tools/profile_bench.sh <tag>      (run on the GPU box from the repository root)
 # 1. rocprofv3 --kernel-trace --stats of the default bench.py (without the CPU baseline leg);
-# 2. per weight setting, two --pmc passes (FETCH_SIZE, WRITE_SIZE: each in its own run) for the HBM traffic of
+# 2. per variant (uniform, integer, integer with look-ups forced), two --pmc passes (FETCH_SIZE, WRITE_SIZE: each in its own run) for the HBM traffic of
 #    the cost-only bench.  Summaries go to gpurun_out/<tag>_*.csv and gpurun_out/<tag>_traffic.json (copy the
 #    latter to profiles/r02_traffic.json: bench.py reads it); raw traces are deleted.
 set -e
@@ -13,12 +13,14 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats -d "$d/stats" --output-format
 f=$(find "$d/stats" -name '*kernel_stats.csv' | head -1)
 python3 tools/prof_summary.py "$f" "rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu ($tag)" > gpurun_out/${tag}_bench_default_stats.csv
 rm -rf "$d/stats"
-for w in uniform integer; do
-  : > gpurun_out/${tag}_${w}_hbm_traffic.csv
+for v in uniform integer integer_table; do
+  w=${v%_table}
+  tab=packed; [ "$v" = integer_table ] && tab=table
+  : > gpurun_out/${tag}_${v}_hbm_traffic.csv
   for c in FETCH_SIZE WRITE_SIZE; do
-    timeout -s KILL 120 rocprofv3 --pmc $c -d "$d/pmc_$c" --output-format csv -- python3 bench.py --no-cpu --no-qubo --single --weights $w > "$d/pmc_${w}_$c.log" 2>&1
+    timeout -s KILL 120 rocprofv3 --pmc $c -d "$d/pmc_$c" --output-format csv -- python3 bench.py --no-cpu --no-qubo --single --weights $w --table $tab > "$d/pmc_${v}_$c.log" 2>&1
     f=$(find "$d/pmc_$c" -name '*counter_collection.csv' | head -1)
-    python3 tools/pmc_summary.py "$f" k_cost_v3 >> gpurun_out/${tag}_${w}_hbm_traffic.csv
+    python3 tools/pmc_summary.py "$f" k_cost_v3 >> gpurun_out/${tag}_${v}_hbm_traffic.csv
     rm -rf "$d/pmc_$c"
   done
 done
