@@ -854,18 +854,28 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_pairs(V3Args p) {
                 }
                 if (lane_on) *reinterpret_cast<uint4*>(strip + lane * 16) = cur;
                 uint32_t au[kRowEdgeChunks], av[kRowEdgeChunks];
+                if (nch >= kRowEdgeChunks) {  // the usual case, without a select per chunk
 #pragma unroll
-                for (int c = 0; c < kRowEdgeChunks; ++c) {  // a chunk the row lacks: one qubit twice
-                    const uint32_t g = c < nch ? gates[c] : 0u;
-                    au[c] = strip[g & 0xFFFFu];
-                    av[c] = strip[g >> 16];
+                    for (int c = 0; c < kRowEdgeChunks; ++c) {
+                        au[c] = strip[gates[c] & 0xFFFFu];
+                        av[c] = strip[gates[c] >> 16];
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < kRowEdgeChunks; ++c) {  // a chunk the row lacks: one qubit twice
+                        const uint32_t g = c < nch ? gates[c] : 0u;
+                        au[c] = strip[g & 0xFFFFu];
+                        av[c] = strip[g >> 16];
+                    }
                 }
                 const uint32_t c0 = cur.x & keep[0], c1 = cur.y & keep[1], c2 = cur.z & keep[2], c3 = cur.w & keep[3];
                 // the gates first: their counts hang on the gathers just issued, and LDS operations complete in
                 // order, so whatever is issued between a gather and its use is waited for as well
                 static_assert(kRowEdgeChunks == 4, "the first four gate chunks of a row are counted two to a register");
-                count_gates2(au[0] | au[1] << 16, av[0] | av[1] << 16);
-                count_gates2(au[2] | au[3] << 16, av[2] | av[3] << 16);
+                // byte 0 of two gathered values into the 16-bit halves of one register
+                auto halves = [](uint32_t x0, uint32_t x1) { return __builtin_amdgcn_perm(x1, x0, 0x0c040c00u); };
+                count_gates2(halves(au[0], au[1]), halves(av[0], av[1]));
+                count_gates2(halves(au[2], au[3]), halves(av[2], av[3]));
                 for (int c = kRowEdgeChunks; c < nch; ++c) {
                     const uint32_t g = sched_lane[s0 + c * kWave];
                     const uint32_t u = strip[g & 0xFFFFu], v = strip[g >> 16];
