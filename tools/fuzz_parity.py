@@ -124,7 +124,11 @@ def main():
         return [pick(2, 80), pick(81, 512), pick(513, 1024), pick(1025, 1600)][pick(0, 3)]
 
     def draw():
-        kind = pick(0, 9)
+        kind = pick(0, 10)
+        if kind == 10:  # long rows, table in LDS, 64 partitions or more: four partitions per wave step
+            integer = bool(pick(0, 1))
+            return "cost_v3_four_partitions", TC.test_cost_v3_four_partitions_per_wave, (gpu, pick(513, 1024), pick(1, 80), pick(2, 256) if integer else pick(2, 64),
+                                                                                         pick(64, 140), integer)
         if kind == 9:
             C = [4, 9, 16, 25][pick(0, 3)]
             return "qubo_energy_fields", TQ.test_energy_and_fields_exact, ((torch, dev), pick(8, 70), pick(1, 7), C, pick(2, 12), pick(0, 1 << 20))
