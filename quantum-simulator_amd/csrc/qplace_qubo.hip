@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <type_traits>
 
 #include "qplace_internal.h"
 
@@ -213,129 +214,201 @@ __global__ __launch_bounds__(256, 2) void k_qubo_kron(KronArgs p) {
     kron_epilogue<ENERGY, WN>(p, acc, vcore + krow0, krow0, P, r0, wm, wn, lane, sbits);
 }
 
-// The same contraction with the states resident: workgroup = (slice, core, 128 replicas).  Its piece of the B
-// operand (128 replicas x P bytes) is read from device memory once and stays in LDS while the workgroup walks
-// all 128-row tiles of `same` (which stream through LDS from the cache, 128 x 128 bytes at a time).  With one
-// workgroup per row tile, as in k_qubo_kron, the states are read once per row tile, and that traffic is
-// what bounds the kernel.  Row pitch of the resident states: P rounded up to 128, plus 16 (an odd number of
-// 16-byte slots: conflict-free ds_read_b128).  Used when that fits LDS beside the `same` tile.
-template <bool ENERGY>
-__global__ __launch_bounds__(256, 2) void k_qubo_kron_resident(KronArgs p) {
-    constexpr int WN = 2;
-    constexpr int kCols = 64 * WN;
-    extern __shared__ __align__(16) int8_t smem_res[];
-    __shared__ __align__(16) int8_t sA[kTile * kPitch];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int work = blockIdx.y, coltile = blockIdx.x;
-    const int t = work / p.m.C, j = work - t * p.m.C;  // work item = (slice, core)
-    const int P = p.m.pitch[t];
-    const int Pp = (P + kTile - 1) / kTile * kTile;
-    const int MT = Pp / kTile;
-    const int bpitch = Pp + 16;
-    const int64_t vcore = p.m.off[t] + (int64_t)j * P;
-    const int r0 = coltile * kCols;
-    int8_t* sB = smem_res;
+// The same contraction with `same` in registers: workgroup = (slice, 64 replicas), 8 waves.  Wave w owns the
+// 32-row tile w of `same[t]` and one 32-replica half of a tile from 8 on, and keeps their MFMA A fragments (up to
+// 2 x 12 x 16 bytes per lane) in registers for the whole kernel; the workgroup then walks the C cores of the slice: the 64 x P bytes of states
+// of a core are the B operand, staged through two LDS buffers from two register sets, so that a tile's loads
+// are issued two tiles before it is used and one barrier per tile suffices.  No operand is re-read from device
+// memory (the states once, `same` once per workgroup from cache), no A fragment is read from LDS, two waves
+// per SIMD overlap one's epilogue with the other's MFMAs, and the energy leaves as one atomic per replica and
+// wave.  For pitches up to 384 (12 tiles of 32).
+constexpr int kRegK = 12;                                          // 32-wide steps along the contraction axis: pitch <= 384
+constexpr int kRegCols = 64;                                       // replicas per workgroup
+constexpr int kRegThreads = 512;
+constexpr int kRegPieces = kRegCols * kRegK * 2 / kRegThreads;     // 16-byte pieces of a states tile per thread
 
-    // the states of this core for the workgroup's replicas -> LDS (zeros past the core's P bytes)
-    const int srow = tid >> 3, spiece = tid & 7;
-    const int8_t* Bb = p.Xt + (size_t)r0 * p.m.Npad + vcore;
-    for (int k0 = 0; k0 < Pp; k0 += kBK) {
-        const bool in_ = k0 + spiece * 16 < P;
+template <bool ENERGY>
+__global__ __launch_bounds__(kRegThreads) void k_qubo_kron_areg(KronArgs p) {
+    extern __shared__ __align__(16) int8_t smem_areg[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int t = blockIdx.y, r0 = blockIdx.x * kRegCols;
+    const int P = p.m.pitch[t], C = p.m.C;
+    const int KT = P / 32;  // K steps, and 32-row tiles of `same`
+    const int Pp = (P + kTile - 1) / kTile * kTile;
+    const int bpitch = P + 16;  // an odd number of 16-byte slots: conflict-free ds_read_b128
+    int8_t* sB0 = smem_areg;
+    int8_t* sB1 = smem_areg + kRegCols * bpitch;
+    int32_t* sLin0 = reinterpret_cast<int32_t*>(smem_areg + 2 * kRegCols * bpitch);
+    int32_t* sLin1 = sLin0 + P;
+
+    // this thread's pieces of a states tile: (replica row, 16-byte piece) -> offsets in device memory and in LDS
+    const int ppr = P / 16;
+    // (offsets of buffer 1 are relative to sB1; a spare slot lies behind both buffers and the linear terms)
+    const int spare = 2 * kRegCols * bpitch + 2 * P * (int)sizeof(int32_t) + tid * 16;
+    int64_t goff[kRegPieces];
+    int loff0[kRegPieces], loff1[kRegPieces];
 #pragma unroll
-        for (int i = 0; i < kCols / 32; ++i) {
-            const int row = srow + 32 * i;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (in_) v = *reinterpret_cast<const uint4*>(Bb + (size_t)row * p.m.Npad + k0 + spiece * 16);
-            *reinterpret_cast<uint4*>(sB + row * bpitch + k0 + spiece * 16) = v;
+    for (int i = 0; i < kRegPieces; ++i) {
+        const int q = tid + kRegThreads * i;
+        const bool on = q < kRegCols * ppr;
+        const int row = on ? q / ppr : 0, pc = on ? q - row * ppr : 0;
+        goff[i] = (int64_t)row * p.m.Npad + pc * 16;
+        loff0[i] = on ? row * bpitch + pc * 16 : spare;
+        loff1[i] = on ? row * bpitch + pc * 16 : spare - kRegCols * bpitch;
+    }
+    // the linear terms of a tile: P / 4 threads load and store 16 bytes each, the others their spare slot
+    const int slin0 = tid < P / 4 ? tid * 4 : (spare - 2 * kRegCols * bpitch) / 4;  // in int32 units from sLin0
+    const int slin1 = tid < P / 4 ? tid * 4 : slin0 - P;
+    const int lin4 = tid < P / 4 ? tid * 4 : 0;
+    const int8_t* Xbase = p.Xt + (size_t)r0 * p.m.Npad + p.m.off[t];
+    const int32_t* Lbase = p.m.linear + p.m.off[t];
+    // (named registers and macros: as arrays the two register sets end up in scratch memory)
+    static_assert(kRegPieces == 3, "three named staging registers per set");
+    uint4 rs0_0, rs0_1, rs0_2, rs1_0, rs1_1, rs1_2;
+    int4 rl0 = make_int4(0, 0, 0, 0), rl1 = make_int4(0, 0, 0, 0);
+    rs0_0 = rs0_1 = rs0_2 = rs1_0 = rs1_1 = rs1_2 = make_uint4(0, 0, 0, 0);
+// every load is issued whatever the thread and the tile (a piece that does not exist reads the tile's first bytes,
+// a tile past the last core reads the last one again): with loads under branches the compiler cannot count how
+// many newer loads are in flight and waits for all of them before a set is stored, prefetch included
+#define QP_AREG_LOAD1(j_, set_, i_) \
+    rs##set_##_##i_ = *reinterpret_cast<const uint4*>(Xbase + (int64_t)min((j_), C - 1) * P + goff[i_])
+#define QP_AREG_LOAD(j_, set_)                                                                                     \
+    do {                                                                                                          \
+        QP_AREG_LOAD1(j_, set_, 0);                                                                               \
+        QP_AREG_LOAD1(j_, set_, 1);                                                                               \
+        QP_AREG_LOAD1(j_, set_, 2);                                                                               \
+        if constexpr (ENERGY) rl##set_ = *reinterpret_cast<const int4*>(Lbase + (int64_t)min((j_), C - 1) * P + lin4); \
+    } while (0)
+// stores are unconditional too (a piece that does not exist goes to a spare slot of the thread's own)
+#define QP_AREG_STORE1(set_, buf_, i_) *reinterpret_cast<uint4*>(sB##buf_ + loff##buf_[i_]) = rs##set_##_##i_
+#define QP_AREG_STORE(set_, buf_)                                                       \
+    do {                                                                               \
+        QP_AREG_STORE1(set_, buf_, 0);                                                 \
+        QP_AREG_STORE1(set_, buf_, 1);                                                 \
+        QP_AREG_STORE1(set_, buf_, 2);                                                 \
+        if constexpr (ENERGY) *reinterpret_cast<int4*>(sLin##buf_ + slin##buf_) = rl##set_;  \
+    } while (0)
+    QP_AREG_LOAD(0, 0);
+    QP_AREG_LOAD(1, 1);
+
+    // Work of a wave: the whole 32-row tile `wave` (both 32-replica halves), and, of the tiles 8.. that are left
+    // when the slice has more than 8, one half: tile 8 + wave / 2, replica half wave & 1.
+    const int mx = 8 + (wave >> 1), bx = wave & 1;
+    const bool extra = mx < KT;
+    // A fragments: lane (row l31 of the tile, 16-byte half h of a 32-byte step)
+    v4i fa[2][kRegK];
+    {
+        const int8_t* Abase = p.m.same + p.m.same_off[t];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int mt = a == 0 ? wave : mx;
+#pragma unroll
+            for (int kk = 0; kk < kRegK; ++kk) {
+                fa[a][kk] = v4i{0, 0, 0, 0};
+                if (mt < KT && kk < KT)
+                    fa[a][kk] = *reinterpret_cast<const v4i*>(Abase + (size_t)(mt * 32 + l31) * Pp + kk * 32 + h * 16);
+            }
         }
     }
-    const int8_t* Abase = p.m.same + p.m.same_off[t];
-    for (int mt = 0; mt < MT; ++mt) {
-        const int krow0 = mt * kTile;
-        v16i acc[2][WN];
+    int esum[3] = {0, 0, 0};  // replica halves 0 and 1 of the own tile, the extra half
+
+    // One tile of states: core j against this wave's rows.  The number of K steps and whether the wave has an extra
+    // half tile are compile-time here, so the body is straight-line code: fragment reads run ahead of the MFMAs and
+    // the epilogue of one accumulator overlaps the MFMAs of the next.
+    auto tile = [&](auto ktc, auto extrac, int j, const int8_t* B, const int32_t* lin) {
+        constexpr int KT_ = decltype(ktc)::value;
+        constexpr bool EXTRA = decltype(extrac)::value;
+        constexpr int NU = EXTRA ? 3 : 2;  // units of 32 rows x 32 replicas
+        v16i acc[NU];
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int u = 0; u < NU; ++u)
 #pragma unroll
-            for (int b = 0; b < WN; ++b)
+            for (int k = 0; k < 16; ++k) acc[u][k] = 0;
+        const int8_t* Bu[3] = {B + l31 * bpitch + h * 16, B + (32 + l31) * bpitch + h * 16, B + (bx * 32 + l31) * bpitch + h * 16};
 #pragma unroll
-                for (int k = 0; k < 16; ++k) acc[a][b][k] = 0;
-        const int8_t* Ab = Abase + (size_t)krow0 * Pp + (size_t)srow * Pp + spiece * 16;
-        uint4 ra0 = *reinterpret_cast<const uint4*>(Ab);
-        uint4 ra1 = *reinterpret_cast<const uint4*>(Ab + (size_t)32 * Pp);
-        uint4 ra2 = *reinterpret_cast<const uint4*>(Ab + (size_t)64 * Pp);
-        uint4 ra3 = *reinterpret_cast<const uint4*>(Ab + (size_t)96 * Pp);
-        for (int k0 = 0; k0 < P; k0 += kBK) {
-            __syncthreads();  // the previous tile of `same` has been consumed (first pass: the states are in place)
-            {
-                int8_t* wa = sA + srow * kPitch + spiece * 16;
-                *reinterpret_cast<uint4*>(wa) = ra0;
-                *reinterpret_cast<uint4*>(wa + 32 * kPitch) = ra1;
-                *reinterpret_cast<uint4*>(wa + 64 * kPitch) = ra2;
-                *reinterpret_cast<uint4*>(wa + 96 * kPitch) = ra3;
-            }
-            __syncthreads();
-            if (k0 + kBK < P) {
-                ra0 = *reinterpret_cast<const uint4*>(Ab + k0 + kBK);
-                ra1 = *reinterpret_cast<const uint4*>(Ab + (size_t)32 * Pp + k0 + kBK);
-                ra2 = *reinterpret_cast<const uint4*>(Ab + (size_t)64 * Pp + k0 + kBK);
-                ra3 = *reinterpret_cast<const uint4*>(Ab + (size_t)96 * Pp + k0 + kBK);
-            }
+        for (int kk = 0; kk < KT_; ++kk) {
+            v4i fb[NU];
 #pragma unroll
-            for (int kk = 0; kk < kBK / 32; ++kk) {
-                if (k0 + kk * 32 >= P) break;
-                v4i fa[2], fb[WN];
-                const int koff = kk * 32 + (lane >> 5) * 16;
+            for (int u = 0; u < NU; ++u) fb[u] = *reinterpret_cast<const v4i*>(Bu[u] + kk * 32);
 #pragma unroll
-                for (int a = 0; a < 2; ++a)
-                    fa[a] = *reinterpret_cast<const v4i*>(sA + (wm * 64 + a * 32 + (lane & 31)) * kPitch + koff);
+            for (int u = 0; u < NU; ++u) acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[u >> 1][kk], fb[u], acc[u], 0, 0, 0);
+        }
+        // accumulator element k of lane l: row (k & 3) + 8 * (k >> 2) + 4 * (l >> 5) of the tile, column l & 31
 #pragma unroll
-                for (int b = 0; b < WN; ++b)
-                    fb[b] = *reinterpret_cast<const v4i*>(sB + (wn * 32 * WN + b * 32 + (lane & 31)) * bpitch + k0 + koff);
+        for (int u = 0; u < NU; ++u) {
+            const int mt = u < 2 ? wave : mx;
+            const int col = (u < 2 ? u : bx) * 32 + l31;
 #pragma unroll
-                for (int a = 0; a < 2; ++a)
+            for (int g = 0; g < 4; ++g) {
+                const int i = mt * 32 + 8 * g + 4 * h;  // four consecutive rows
+                if constexpr (ENERGY) {
+                    const int4 l4 = *reinterpret_cast<const int4*>(lin + i);
+                    const int l2[4] = {2 * l4.x, 2 * l4.y, 2 * l4.z, 2 * l4.w};
+                    // state bytes are 0 or 1 (the MFMA multiplies by the byte as it is, so does this)
+                    const uint32_t x4 = *reinterpret_cast<const uint32_t*>(B + col * bpitch + i);
 #pragma unroll
-                    for (int b = 0; b < WN; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[a], fb[b], acc[a][b], 0, 0, 0);
+                    for (int q = 0; q < 4; ++q) esum[u] += __mul24(acc[u][4 * g + q] + l2[q], (int)((x4 >> (8 * q)) & 0xFFu));
+                } else {
+                    const int64_t v = p.m.off[t] + (int64_t)j * P + i;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) p.out[(size_t)(v + q) * p.R + r0 + col] = acc[u][4 * g + q];
+                }
             }
         }
-        // epilogue of this row tile; the states of its rows are bytes krow0 + i of the resident piece
-        const int h = lane >> 5;
-        const int64_t v0 = vcore + krow0;
-        if constexpr (!ENERGY) {
+    };
+    // the walk over the cores, once per (K steps, extra half tile or not)
+    auto walk = [&](auto ktc, auto twoc) {
+        const bool rows = wave < decltype(ktc)::value;  // a wave without rows only stages
+        QP_AREG_STORE(0, 0);
+        QP_AREG_LOAD(2, 0);
+        int j = 0;
+        for (; j + 1 < C; j += 2) {  // no branch around a load or a store in here: the waits the compiler places stay exact
+            __syncthreads();  // tile j is in buffer 0, and every wave is done with buffer 1
+            QP_AREG_STORE(1, 1);
+            QP_AREG_LOAD(j + 3, 1);
+            if (rows) tile(ktc, twoc, j, sB0, sLin0);
+            __syncthreads();
+            QP_AREG_STORE(0, 0);  // tile j + 2 (the last tile once more when there is none: never used)
+            QP_AREG_LOAD(j + 4, 0);
+            if (rows) tile(ktc, twoc, j + 1, sB1, sLin1);
+        }
+        if (j < C) {
+            __syncthreads();
+            if (rows) tile(ktc, twoc, j, sB0, sLin0);
+        }
+    };
+#define QP_AREG_CASE(k_)                                                                         \
+    case k_:                                                                                    \
+        if (k_ > 8 && extra) walk(std::integral_constant<int, k_>{}, std::true_type{});         \
+        else walk(std::integral_constant<int, k_>{}, std::false_type{});                        \
+        break
+    switch (KT) {
+        QP_AREG_CASE(1);
+        QP_AREG_CASE(2);
+        QP_AREG_CASE(3);
+        QP_AREG_CASE(4);
+        QP_AREG_CASE(5);
+        QP_AREG_CASE(6);
+        QP_AREG_CASE(7);
+        QP_AREG_CASE(8);
+        QP_AREG_CASE(9);
+        QP_AREG_CASE(10);
+        QP_AREG_CASE(11);
+        QP_AREG_CASE(12);
+        default: break;
+    }
+#undef QP_AREG_CASE
+#undef QP_AREG_LOAD
+#undef QP_AREG_LOAD1
+#undef QP_AREG_STORE
+#undef QP_AREG_STORE1
+    if constexpr (ENERGY) {
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < WN; ++b) {
-                    const int col = r0 + wn * 32 * WN + b * 32 + (lane & 31);
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) {
-                        const int i = wm * 64 + a * 32 + (k & 3) + 8 * (k >> 2) + 4 * h;
-                        if (krow0 + i < P) p.out[(size_t)(v0 + i) * p.R + col] = acc[a][b][k];
-                    }
-                }
-        } else {
-#pragma unroll
-            for (int b = 0; b < WN; ++b) {
-                const int lcol = wn * 32 * WN + b * 32 + (lane & 31);
-                int s = 0;
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int i = wm * 64 + a * 32 + 8 * g + 4 * h;  // four consecutive rows; P is a multiple of 32
-                        if (krow0 + i < P) {
-                            const uint32_t x4 = *reinterpret_cast<const uint32_t*>(sB + lcol * bpitch + krow0 + i);
-                            const int4 lin = *reinterpret_cast<const int4*>(p.m.linear + v0 + i);
-                            const int l4[4] = {lin.x, lin.y, lin.z, lin.w};
-#pragma unroll
-                            for (int q = 0; q < 4; ++q)
-                                if ((x4 >> (8 * q)) & 1u) s += 2 * l4[q] + acc[a][b][4 * g + q];
-                        }
-                    }
-                s += __shfl_xor(s, 32, 64);
-                if (h == 0) atomicAdd(&p.out[r0 + lcol], s);
-            }
+        for (int u = 0; u < 3; ++u) {
+            const int s = esum[u] + __shfl_xor(esum[u], 32, 64);
+            const int col = (u < 2 ? u : bx) * 32 + l31;
+            if (h == 0 && wave < KT && (u < 2 || extra)) atomicAdd(&p.out[r0 + col], s);
         }
     }
 }
@@ -710,17 +783,16 @@ KronArgs kron_args(const QpQuboKron* m, const int8_t* Xt, int32_t R, int32_t* ou
     return a;
 }
 
-// The contraction: states resident in LDS when the widest slice's piece fits twice per CU, else a workgroup
-// per row tile.  max_pitch = largest pitch[t] (the host side knows it: nmax + cap rounded up to 32).
+// The contraction: `same` in registers while the widest slice's pitch allows it (nmax + cap rounded up to 32, at
+// most 384), else a workgroup per 128-row tile with both operands staged through LDS.
 template <bool ENERGY>
 int launch_kron(const KronArgs& a, hipStream_t stream) {
     const int P = (a.m.nmax + a.m.cap + 31) / 32 * 32;
-    const int Pp = (P + kTile - 1) / kTile * kTile;
-    const size_t res = (size_t)128 * (Pp + 16);
-    if (res + (size_t)kTile * kPitch <= 78 * 1024) {
-        auto kern = k_qubo_kron_resident<ENERGY>;
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)res));
-        kern<<<dim3(a.R / 128, a.m.T * a.m.C), 256, res, stream>>>(a);
+    if (P <= 32 * kRegK) {
+        auto kern = k_qubo_kron_areg<ENERGY>;
+        const size_t lds = (size_t)2 * kRegCols * (P + 16) + (size_t)2 * P * sizeof(int32_t) + (size_t)kRegThreads * 16;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        kern<<<dim3(a.R / kRegCols, a.m.T), kRegThreads, lds, stream>>>(a);
     } else if (a.R % 256 == 0) {
         k_qubo_kron<ENERGY, 4><<<dim3(a.R / 256, a.m.n_tiles), 256, 0, stream>>>(a);
     } else {

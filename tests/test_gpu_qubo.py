@@ -47,8 +47,12 @@ def _oracle_energy(qm, names, state):
     return O.qubo_energy(act, inter, qm.C, qm.cap, qm.H.tolist(), x, y), x
 
 
-@pytest.mark.parametrize("Q,T,C,cap,seed", [(6, 3, 4, 3, 1), (20, 5, 4, 6, 2), (40, 4, 9, 5, 3), (33, 6, 16, 3, 4)])
+@pytest.mark.parametrize("Q,T,C,cap,seed", [(6, 3, 4, 3, 1), (20, 5, 4, 6, 2), (40, 4, 9, 5, 3), (33, 6, 16, 3, 4),
+                                            (400, 2, 16, 32, 9), (500, 2, 16, 32, 11)])
 def test_energy_and_fields_exact(gpu, Q, T, C, cap, seed):
+    """Random states against the integer restatement.  The two large cases have slices of 384 and 288, and of more
+    than 384 state bytes per core: up to 384 the contraction keeps the coupling matrix in registers (12 K steps
+    with extra half tiles on every wave, 9 with two), above that it stages both operands through LDS."""
     torch, dev = gpu
     from quantum_simulator_amd.qubo import DeviceQubo
     qm, names = _model(Q, T, C, cap, seed)
