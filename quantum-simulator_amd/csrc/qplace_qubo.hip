@@ -257,6 +257,21 @@ __global__ __launch_bounds__(kRegThreads) void k_qubo_kron_areg(KronArgs p) {
         loff0[i] = on ? row * bpitch + pc * 16 : spare;
         loff1[i] = on ? row * bpitch + pc * 16 : spare - kRegCols * bpitch;
     }
+    // Core masks, built on the way: the state bytes of core j (0 or 1) are OR-ed, shifted left by j & 7, into a
+    // packed copy of the tile per group of 8 cores (byte k of group g = bits 8g..8g+7 of qubit k's mask), each thread
+    // into its own pieces; after the last core the workgroup unpacks them into masks[t][k][r].
+    const int mask_base = 2 * kRegCols * bpitch + 2 * P * (int)sizeof(int32_t) + kRegThreads * 16;
+    const int NG = (C + 7) / 8;
+    int moff[kRegPieces], mstep[kRegPieces];
+#pragma unroll
+    for (int i = 0; i < kRegPieces; ++i) {
+        const int q = tid + kRegThreads * i;
+        const bool on = q < kRegCols * ppr;
+        moff[i] = on ? mask_base + q * 16 : spare;  // dense: row * P + piece * 16 = q * 16
+        mstep[i] = on ? kRegCols * P : 0;           // a piece that does not exist keeps hitting the spare slot
+        for (int g = 0; g < NG; ++g)
+            if (on) *reinterpret_cast<uint4*>(smem_areg + moff[i] + g * mstep[i]) = make_uint4(0, 0, 0, 0);
+    }
     // the linear terms of a tile: P / 4 threads load and store 16 bytes each, the others their spare slot
     const int slin0 = tid < P / 4 ? tid * 4 : (spare - 2 * kRegCols * bpitch) / 4;  // in int32 units from sLin0
     const int slin1 = tid < P / 4 ? tid * 4 : slin0 - P;
@@ -281,12 +296,23 @@ __global__ __launch_bounds__(kRegThreads) void k_qubo_kron_areg(KronArgs p) {
         if constexpr (ENERGY) rl##set_ = *reinterpret_cast<const int4*>(Lbase + (int64_t)min((j_), C - 1) * P + lin4); \
     } while (0)
 // stores are unconditional too (a piece that does not exist goes to a spare slot of the thread's own)
-#define QP_AREG_STORE1(set_, buf_, i_) *reinterpret_cast<uint4*>(sB##buf_ + loff##buf_[i_]) = rs##set_##_##i_
-#define QP_AREG_STORE(set_, buf_)                                                       \
+#define QP_AREG_STORE1(set_, buf_, i_, jt_)                                                        \
+    do {                                                                                          \
+        *reinterpret_cast<uint4*>(sB##buf_ + loff##buf_[i_]) = rs##set_##_##i_;                   \
+        uint4* mp_ = reinterpret_cast<uint4*>(smem_areg + moff[i_] + ((jt_) >> 3) * mstep[i_]);  \
+        uint4 mv_ = *mp_;                                                                         \
+        mv_.x |= rs##set_##_##i_.x << ((jt_) & 7);                                                \
+        mv_.y |= rs##set_##_##i_.y << ((jt_) & 7);                                                \
+        mv_.z |= rs##set_##_##i_.z << ((jt_) & 7);                                                \
+        mv_.w |= rs##set_##_##i_.w << ((jt_) & 7);                                                \
+        *mp_ = mv_;                                                                               \
+    } while (0)
+#define QP_AREG_STORE(set_, buf_, j_)                                                   \
     do {                                                                               \
-        QP_AREG_STORE1(set_, buf_, 0);                                                 \
-        QP_AREG_STORE1(set_, buf_, 1);                                                 \
-        QP_AREG_STORE1(set_, buf_, 2);                                                 \
+        const int jt_ = min((j_), C - 1); /* a tile stored twice ORs the same bits */   \
+        QP_AREG_STORE1(set_, buf_, 0, jt_);                                            \
+        QP_AREG_STORE1(set_, buf_, 1, jt_);                                            \
+        QP_AREG_STORE1(set_, buf_, 2, jt_);                                            \
         if constexpr (ENERGY) *reinterpret_cast<int4*>(sLin##buf_ + slin##buf_) = rl##set_;  \
     } while (0)
     QP_AREG_LOAD(0, 0);
@@ -296,27 +322,12 @@ __global__ __launch_bounds__(kRegThreads) void k_qubo_kron_areg(KronArgs p) {
     // when the slice has more than 8, one half: tile 8 + wave / 2, replica half wave & 1.
     const int mx = 8 + (wave >> 1), bx = wave & 1;
     const bool extra = mx < KT;
-    // A fragments: lane (row l31 of the tile, 16-byte half h of a 32-byte step)
-    v4i fa[2][kRegK];
-    {
-        const int8_t* Abase = p.m.same + p.m.same_off[t];
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const int mt = a == 0 ? wave : mx;
-#pragma unroll
-            for (int kk = 0; kk < kRegK; ++kk) {
-                fa[a][kk] = v4i{0, 0, 0, 0};
-                if (mt < KT && kk < KT)
-                    fa[a][kk] = *reinterpret_cast<const v4i*>(Abase + (size_t)(mt * 32 + l31) * Pp + kk * 32 + h * 16);
-            }
-        }
-    }
     int esum[3] = {0, 0, 0};  // replica halves 0 and 1 of the own tile, the extra half
 
     // One tile of states: core j against this wave's rows.  The number of K steps and whether the wave has an extra
     // half tile are compile-time here, so the body is straight-line code: fragment reads run ahead of the MFMAs and
     // the epilogue of one accumulator overlaps the MFMAs of the next.
-    auto tile = [&](auto ktc, auto extrac, int j, const int8_t* B, const int32_t* lin) {
+    auto tile = [&](auto ktc, auto extrac, const auto& fa, int j, const int8_t* B, const int32_t* lin) {
         constexpr int KT_ = decltype(ktc)::value;
         constexpr bool EXTRA = decltype(extrac)::value;
         constexpr int NU = EXTRA ? 3 : 2;  // units of 32 rows x 32 replicas
@@ -359,23 +370,36 @@ __global__ __launch_bounds__(kRegThreads) void k_qubo_kron_areg(KronArgs p) {
     };
     // the walk over the cores, once per (K steps, extra half tile or not)
     auto walk = [&](auto ktc, auto twoc) {
-        const bool rows = wave < decltype(ktc)::value;  // a wave without rows only stages
-        QP_AREG_STORE(0, 0);
+        constexpr int KT_ = decltype(ktc)::value;
+        const bool rows = wave < KT_;  // a wave without rows only stages
+        // A fragments of this wave's tile (and of the extra one): lane (row l31, 16-byte half h of a 32-byte step)
+        v4i fa[decltype(twoc)::value ? 2 : 1][KT_];
+        {
+            const int8_t* Abase = p.m.same + p.m.same_off[t];
+#pragma unroll
+            for (int a = 0; a < (decltype(twoc)::value ? 2 : 1); ++a) {
+                const int mt = min(a == 0 ? wave : mx, KT_ - 1);  // (a wave without rows loads the last tile and never uses it)
+#pragma unroll
+                for (int kk = 0; kk < KT_; ++kk)
+                    fa[a][kk] = *reinterpret_cast<const v4i*>(Abase + (size_t)(mt * 32 + l31) * Pp + kk * 32 + h * 16);
+            }
+        }
+        QP_AREG_STORE(0, 0, 0);
         QP_AREG_LOAD(2, 0);
         int j = 0;
         for (; j + 1 < C; j += 2) {  // no branch around a load or a store in here: the waits the compiler places stay exact
             __syncthreads();  // tile j is in buffer 0, and every wave is done with buffer 1
-            QP_AREG_STORE(1, 1);
+            QP_AREG_STORE(1, 1, j + 1);
             QP_AREG_LOAD(j + 3, 1);
-            if (rows) tile(ktc, twoc, j, sB0, sLin0);
+            if (rows) tile(ktc, twoc, fa, j, sB0, sLin0);
             __syncthreads();
-            QP_AREG_STORE(0, 0);  // tile j + 2 (the last tile once more when there is none: never used)
+            QP_AREG_STORE(0, 0, j + 2);  // (the last tile once more when there is none: never used)
             QP_AREG_LOAD(j + 4, 0);
-            if (rows) tile(ktc, twoc, j + 1, sB1, sLin1);
+            if (rows) tile(ktc, twoc, fa, j + 1, sB1, sLin1);
         }
         if (j < C) {
             __syncthreads();
-            if (rows) tile(ktc, twoc, j, sB0, sLin0);
+            if (rows) tile(ktc, twoc, fa, j, sB0, sLin0);
         }
     };
 #define QP_AREG_CASE(k_)                                                                         \
@@ -403,6 +427,24 @@ __global__ __launch_bounds__(kRegThreads) void k_qubo_kron_areg(KronArgs p) {
 #undef QP_AREG_LOAD1
 #undef QP_AREG_STORE
 #undef QP_AREG_STORE1
+    // the masks of the slice's qubits for this workgroup's replicas: lane = replica, 256 contiguous bytes per qubit
+    __syncthreads();
+    {
+        const int n = p.m.n[t];
+        const uint32_t* packed = reinterpret_cast<const uint32_t*>(smem_areg + mask_base) + lane * (P / 4);
+        uint32_t* mout = p.masks + (size_t)t * p.m.nmax * p.R + r0 + lane;
+        for (int kd = wave; kd * 4 < n; kd += kRegThreads / 64) {
+            uint32_t m4[4] = {0, 0, 0, 0};
+            for (int g = 0; g < NG; ++g) {
+                const uint32_t w = packed[g * (kRegCols * P / 4) + kd];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) m4[b] |= ((w >> (8 * b)) & 0xFFu) << (8 * g);
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                if (kd * 4 + b < n) mout[(size_t)(kd * 4 + b) * p.R] = m4[b];
+        }
+    }
     if constexpr (ENERGY) {
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
@@ -783,29 +825,30 @@ KronArgs kron_args(const QpQuboKron* m, const int8_t* Xt, int32_t R, int32_t* ou
     return a;
 }
 
+int launch_bits(const KronArgs& a, hipStream_t stream) {
+    const size_t lds = (size_t)kBitsR * (a.m.C * kBitsK + 4);
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_qubo_bits), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    k_qubo_bits<<<dim3(a.R / kBitsR, a.m.T, (a.m.nmax + kBitsK - 1) / kBitsK), 256, lds, stream>>>(a);
+    HIP_TRY(hipGetLastError());
+    return QP_OK;
+}
+
 // The contraction: `same` in registers while the widest slice's pitch allows it (nmax + cap rounded up to 32, at
 // most 384), else a workgroup per 128-row tile with both operands staged through LDS.
 template <bool ENERGY>
 int launch_kron(const KronArgs& a, hipStream_t stream) {
     const int P = (a.m.nmax + a.m.cap + 31) / 32 * 32;
-    if (P <= 32 * kRegK) {
+    if (P <= 32 * kRegK) {  // also writes the core masks
         auto kern = k_qubo_kron_areg<ENERGY>;
-        const size_t lds = (size_t)2 * kRegCols * (P + 16) + (size_t)2 * P * sizeof(int32_t) + (size_t)kRegThreads * 16;
+        const size_t lds = (size_t)2 * kRegCols * (P + 16) + (size_t)2 * P * sizeof(int32_t) + (size_t)kRegThreads * 16 +
+                           (size_t)((a.m.C + 7) / 8) * kRegCols * P;
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         kern<<<dim3(a.R / kRegCols, a.m.T), kRegThreads, lds, stream>>>(a);
-    } else if (a.R % 256 == 0) {
-        k_qubo_kron<ENERGY, 4><<<dim3(a.R / 256, a.m.n_tiles), 256, 0, stream>>>(a);
     } else {
-        k_qubo_kron<ENERGY, 2><<<dim3(a.R / 128, a.m.n_tiles), 256, 0, stream>>>(a);
+        if (int rc = launch_bits(a, stream)) return rc;
+        if (a.R % 256 == 0) k_qubo_kron<ENERGY, 4><<<dim3(a.R / 256, a.m.n_tiles), 256, 0, stream>>>(a);
+        else k_qubo_kron<ENERGY, 2><<<dim3(a.R / 128, a.m.n_tiles), 256, 0, stream>>>(a);
     }
-    HIP_TRY(hipGetLastError());
-    return QP_OK;
-}
-
-int launch_bits(const KronArgs& a, hipStream_t stream) {
-    const size_t lds = (size_t)kBitsR * (a.m.C * kBitsK + 4);
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_qubo_bits), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    k_qubo_bits<<<dim3(a.R / kBitsR, a.m.T, (a.m.nmax + kBitsK - 1) / kBitsK), 256, lds, stream>>>(a);
     HIP_TRY(hipGetLastError());
     return QP_OK;
 }
@@ -823,8 +866,7 @@ extern "C" int qp_qubo_fields_i32(const QpQuboKron* m, const int8_t* Xt, int32_t
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const KronArgs a = kron_args(m, Xt, R, F, ws);
     HIP_TRY(hipMemsetAsync(F, 0, (size_t)m->Npad * R * sizeof(int32_t), stream));  // padding rows are never written
-    if (int rc = launch_bits(a, stream)) return rc;
-    if (int rc = launch_kron<false>(a, stream)) return rc;
+    if (int rc = launch_kron<false>(a, stream)) return rc;  // (and the core masks)
     k_qubo_extra_fields<<<dim3((R + 255) / 256, m->T, (m->nmax + 15) / 16), 256, 0, stream>>>(a);
     HIP_TRY(hipGetLastError());
     return QP_OK;
@@ -836,8 +878,7 @@ extern "C" int qp_qubo_energy_i32(const QpQuboKron* m, const int8_t* Xt, int32_t
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const KronArgs a = kron_args(m, Xt, R, energy, ws);
     HIP_TRY(hipMemsetAsync(energy, 0, (size_t)R * sizeof(int32_t), stream));
-    if (int rc = launch_bits(a, stream)) return rc;
-    if (int rc = launch_kron<true>(a, stream)) return rc;
+    if (int rc = launch_kron<true>(a, stream)) return rc;  // (and the core masks)
     k_qubo_extra_energy<<<dim3((R + 255) / 256, m->T, (m->nmax + kExtraK - 1) / kExtraK), 256, 0, stream>>>(a);
     HIP_TRY(hipGetLastError());
     k_qubo_finish<<<(R + 255) / 256, 256, 0, stream>>>(energy, R, m->constant);
