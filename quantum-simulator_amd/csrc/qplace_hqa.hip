@@ -23,10 +23,11 @@ namespace {
 
 inline size_t up16(size_t x) { return (x + 15) & ~(size_t)15; }
 
-// Bytes of one instance's share of a lane's pinned slab: live row, op list, core list, the two counts, the table
-// index, the matrix.
+// Bytes of one instance's share of a lane's pinned slab: resolved ops (16 bytes each), core list, the two counts,
+// the table index, the matrix.
 size_t instance_bytes(int32_t ldq, int32_t C, int32_t max_ops) {
-    return up16((size_t)ldq) + up16((size_t)max_ops * 4) + up16((size_t)C) + 16 + up16((size_t)max_ops * C * 8);  // 16: two counts and the table index
+    (void)ldq;
+    return (size_t)max_ops * 16 + up16((size_t)C) + 16 + up16((size_t)max_ops * C * 8);  // 16: two counts and the table index
 }
 
 struct Batch {
@@ -37,6 +38,7 @@ struct Batch {
     const int32_t* sep;
     const QpEdge* edges;
     const double* D;       // host [S][C*C]
+    const int16_t* lookahead;  // host copy of QpCircuit.lookahead: [nE][6] partner qubits or -1
     const uint8_t* initial;
     uint8_t* out;
     int32_t rows_out;
@@ -59,13 +61,11 @@ void lane_fail(Lane& ln, int rc, const char* what, const char* detail) {
 void run_lane(const Batch& bx, Lane& ln) {
     if (hipSetDevice(bx.device) != hipSuccess) return lane_fail(ln, QP_EHIP, "hipSetDevice", "failed on a worker thread");
     const int64_t nb = ln.b1 - ln.b0;
-    const int32_t Q = bx.Q, C = bx.C, cap = bx.cap, ldq = bx.ldq, T = bx.T;
-    // slab layout: the same arrays qp_cost_matrix takes, sized for all of the lane's instances
+    const int32_t Q = bx.Q, C = bx.C, cap = bx.cap, T = bx.T;
+    // slab layout: what the cost-matrix kernel reads and writes, sized for all of the lane's instances
     uint8_t* p = ln.slab;
-    uint8_t* pa = p;
-    p += up16((size_t)nb * ldq);
-    int32_t* pops = reinterpret_cast<int32_t*>(p);
-    p += up16((size_t)nb * bx.max_ops * 4);
+    int16_t* pinfo = reinterpret_cast<int16_t*>(p);
+    p += (size_t)nb * bx.max_ops * 16;
     uint8_t* pavail = p;
     p += up16((size_t)nb * C);
     int32_t* pnops = reinterpret_cast<int32_t*>(p);
@@ -79,14 +79,13 @@ void run_lane(const Batch& bx, Lane& ln) {
     std::vector<uint8_t> a((size_t)nb * Q);
     std::vector<int64_t> occ((size_t)nb * C);
     std::vector<uint8_t> rem((size_t)nb * bx.max_ops);
+    std::vector<int32_t> ops((size_t)nb * bx.max_ops);  // per launched instance: the slice-local gates of its matrix rows
     std::vector<int32_t> nrem(nb), budget(nb), spent(nb), go, rr(std::max(bx.max_ops, C)), cc(std::max(bx.max_ops, C));
     struct WorkHolder {  // freed on every way out of the lane
         qp::LsapWork* w = qp::lsap_work_new();
         ~WorkHolder() { qp::lsap_work_free(w); }
     } holder;
     qp::LsapWork* work = holder.w;
-    memset(pa, 0, (size_t)nb * ldq);  // pad bytes of the live rows stay zero
-
     for (int64_t k = 0; k < nb; ++k) {
         const uint8_t* src = bx.initial + (size_t)(ln.b0 + k) * Q;
         memcpy(a.data() + (size_t)k * Q, src, Q);
@@ -132,14 +131,23 @@ void run_lane(const Batch& bx, Lane& ln) {
             const int32_t ng = (int32_t)go.size();
             for (int32_t g = 0; g < ng; ++g) {
                 const int64_t k = go[g];
-                memcpy(pa + (size_t)g * ldq, a.data() + (size_t)k * Q, Q);
+                const uint8_t* ak = a.data() + (size_t)k * Q;
                 const uint8_t* rk = rem.data() + (size_t)k * bx.max_ops;
-                int32_t* og = pops + (size_t)g * E;
+                int32_t* og = ops.data() + (size_t)g * E;
+                int16_t* ig = pinfo + (size_t)g * E * 8;
                 int32_t n = 0;
-                for (int32_t e = 0; e < E; ++e)
-                    if (rk[e]) og[n++] = e0 + e;
+                for (int32_t e = 0; e < E; ++e) {
+                    if (!rk[e]) continue;
+                    // the op's row of the matrix: the cores of its look-ahead partners and of its own qubits, resolved here
+                    // so that the kernel reads nothing that hangs on another load from this (host) memory
+                    const int16_t* la = bx.lookahead + (size_t)(e0 + e) * 6;
+                    int16_t* rec = ig + (size_t)n * 8;
+                    for (int s = 0; s < 6; ++s) rec[s] = la[s] >= 0 ? (int16_t)ak[la[s]] : (int16_t)-1;
+                    rec[6] = ak[ed[e].u];
+                    rec[7] = ak[ed[e].v];
+                    og[n++] = e;
+                }
                 pnops[g] = n;
-                for (int32_t e = n; e < E; ++e) og[e] = e0;
                 const int64_t* ok = occ.data() + (size_t)k * C;
                 uint8_t* ag = pavail + (size_t)g * C;
                 int32_t m = 0;
@@ -148,9 +156,8 @@ void run_lane(const Batch& bx, Lane& ln) {
                 pnav[g] = m;
                 ptab[g] = bx.tab ? bx.tab[ln.b0 + k] : 0;
             }
-            const int rc = qp_cost_matrix_multi(bx.kind, bx.circ, bx.tables, bx.S, C, ptab, ng, pa, ldq, pops, pnops, E, pavail,
-                                                pnav, pcost, ln.stream);
-            if (rc != QP_OK) return lane_fail(ln, rc, "qp_cost_matrix_multi", qp_last_error());
+            const int rc = qp::cost_matrix_resolved(bx.kind, bx.tables, C, ptab, ng, pinfo, pnops, E, pavail, pnav, pcost, ln.stream);
+            if (rc != QP_OK) return lane_fail(ln, rc, "cost matrix launch", qp_last_error());
             // wait for the matrices: poll the stream (an interrupt-driven wait costs more than the kernel)
             hipError_t st;
             unsigned spins = 0;
@@ -169,12 +176,12 @@ void run_lane(const Batch& bx, Lane& ln) {
                 uint8_t* ak = a.data() + (size_t)k * Q;
                 int64_t* ok = occ.data() + (size_t)k * C;
                 uint8_t* rk = rem.data() + (size_t)k * bx.max_ops;
-                const int32_t* og = pops + (size_t)g * E;
+                const int32_t* og = ops.data() + (size_t)g * E;
                 const uint8_t* ag = pavail + (size_t)g * C;
                 const int32_t pairs = std::min(n_ops, n_av);
                 for (int32_t i = 0; i < pairs; ++i) {
                     if (M[(size_t)rr[i] * C + cc[i]] == std::numeric_limits<double>::infinity()) continue;
-                    const int32_t e = og[rr[i]] - e0;
+                    const int32_t e = og[rr[i]];
                     const uint8_t core = ag[cc[i]];
                     const int32_t u = ed[e].u, v = ed[e].v;
                     --ok[ak[u]];
@@ -196,7 +203,7 @@ void run_lane(const Batch& bx, Lane& ln) {
 
 extern "C" size_t qp_hqa_place_pinned_bytes(int32_t ldq, int32_t C, int32_t max_slice_edges, int64_t B, int32_t lanes) {
     if (ldq <= 0 || C <= 0 || max_slice_edges < 0 || B <= 0 || lanes <= 0) return 0;
-    // every array of a lane is rounded up on its own: 6 arrays of up to 15 bytes of padding per lane
+    // every array of a lane is rounded up on its own: 5 arrays of up to 15 bytes of padding per lane
     return (size_t)B * instance_bytes(ldq, C, std::max(max_slice_edges, 1)) + (size_t)lanes * 128;
 }
 
@@ -238,6 +245,13 @@ extern "C" int qp_hqa_place_batch_multi(int32_t kind, const QpCircuit* circ, con
         for (int32_t q = 0; q < bx.Q; ++q)
             if (initial[(size_t)b * bx.Q + q] >= bx.C) return qp::fail(QP_EINVAL, "%s: initial holds a core index outside the table", fn);
     HIP_TRY(hipGetDevice(&bx.device));
+    // the look-ahead partners of every gate, for the lanes to resolve cores on the host
+    std::vector<int16_t> lookahead((size_t)std::max(circ->nE, 1) * 6, (int16_t)-1);
+    if (circ->nE > 0) {
+        if (!circ->lookahead) return qp::fail(QP_EINVAL, "%s: circuit look-ahead table missing", fn);
+        HIP_TRY(hipMemcpy(lookahead.data(), circ->lookahead, (size_t)circ->nE * 6 * sizeof(int16_t), hipMemcpyDeviceToHost));
+    }
+    bx.lookahead = lookahead.data();
     lanes = (int32_t)std::min<int64_t>(lanes, B);
     const size_t per = instance_bytes(bx.ldq, bx.C, bx.max_ops);
     if (pinned_bytes < (size_t)B * per + (size_t)lanes * 128)

@@ -16,6 +16,14 @@ LsapWork* lsap_work_new();
 void lsap_work_free(LsapWork*);
 int lsap(int32_t nr, int32_t nc, const double* cost, int32_t ld, int32_t* row_out, int32_t* col_out, LsapWork* work);
 
+// qp_cost_matrix_multi (HQA / TRHQA) for callers that hold the live rows themselves: instead of op ids and rows,
+// resolved[B][max_ops][8] holds per op the cores of its up to six look-ahead partners (-1 = none, in the order of
+// QpCircuit.lookahead) and of its own two qubits.  Every pointer but `tables` may be device-visible host memory:
+// the kernel then needs one round of loads from it, not a chain.  Device translation units only.
+int cost_matrix_resolved(int32_t kind, const double* tables, int32_t C, const int32_t* tab_index, int64_t B,
+                         const int16_t* resolved, const int32_t* n_ops, int32_t max_ops, const uint8_t* avail,
+                         const int32_t* n_avail, double* cost_out, void* stream);
+
 // The make-space step of qp_make_space on one assignment row and its occupancy counts.
 void make_space_row(uint8_t* a, int64_t* occ, int32_t Q, int32_t C, int32_t cap, const double* D);
 }  // namespace qp

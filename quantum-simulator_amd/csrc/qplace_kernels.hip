@@ -1460,6 +1460,9 @@ struct CmArgs {
     double* out;
     int32_t C, ldq, max_ops, kind;
     const int32_t* tab;  // optional: instance b uses the table D + tab[b] * C * C
+    // optional: [B][max_ops][8] the cores of every op resolved by the caller (partners 0..5 or -1, then the cores of
+    // the op's own two qubits): then ops, a and the circuit tables are not read
+    const int16_t* resolved;
 };
 
 __device__ inline double pymax(double a, double b) { return b > a ? b : a; }  // Python's max(a, b)
@@ -1493,13 +1496,29 @@ __global__ __launch_bounds__(256) void k_cost_matrix(CmArgs p) {
     __shared__ uint32_t near_mask[kCmOps][8];            // bit c: core c holds a look-ahead partner
     __shared__ double att_near[kCmOps][6];               // attraction seen from the core of partner k
     const int64_t b = blockIdx.y;
-    const int n_ops = p.n_ops[b], n_av = p.n_avail[b];
     const int i0 = blockIdx.x * kCmOps;
+    const int C = p.C;
+    // With resolved ops every input of the workgroup is requested here, before anything depends on a loaded value:
+    // the caller's arrays may live in host memory, where each dependent load is a round trip over the bus.
+    uint4 rec = make_uint4(0, 0, 0, 0);
+    if (p.resolved && threadIdx.x < kCmOps)
+        rec = *reinterpret_cast<const uint4*>(p.resolved + ((size_t)b * p.max_ops + min(i0 + (int)threadIdx.x, p.max_ops - 1)) * 8);
+    const int32_t c_first = p.avail[(size_t)b * C + min((int)threadIdx.x, C - 1)];  // the core of this thread's column
+    const size_t tab_off = p.tab ? (size_t)p.tab[b] * C * C : (size_t)0;
+    const int n_ops = p.n_ops[b], n_av = p.n_avail[b];
     if (i0 >= n_ops) return;
     const int i1 = min(n_ops, i0 + kCmOps);
     const uint8_t* a = p.a + (size_t)b * p.ldq;
-    const int C = p.C;
-    if (threadIdx.x < kCmOps * 8) {
+    if (p.resolved) {
+        if (threadIdx.x < kCmOps) {
+            const uint32_t w[4] = {rec.x, rec.y, rec.z, rec.w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int v = (int)(int16_t)(w[k >> 1] >> (16 * (k & 1)));
+                opinfo[threadIdx.x][k] = (i0 + (int)threadIdx.x < i1) ? min(v, C - 1) : -1;
+            }
+        }
+    } else if (threadIdx.x < kCmOps * 8) {
         const int i = i0 + (threadIdx.x >> 3), k = threadIdx.x & 7;
         int32_t v = -1;
         if (i < i1) {
@@ -1532,8 +1551,8 @@ __global__ __launch_bounds__(256) void k_cost_matrix(CmArgs p) {
     }
     __syncthreads();
     for (int j = threadIdx.x; j < n_av; j += blockDim.x) {
-        const int32_t c = min((int32_t)p.avail[(size_t)b * C + j], C - 1);
-        const double* Dc = p.D + (p.tab ? (size_t)p.tab[b] * C * C : (size_t)0) + c;  // column c of the instance's table
+        const int32_t c = min(j == (int)threadIdx.x ? c_first : (int32_t)p.avail[(size_t)b * C + j], C - 1);
+        const double* Dc = p.D + tab_off + c;  // column c of the instance's table
         double* outp = p.out + ((size_t)b * p.max_ops + i0) * C + j;
         // four ops at a time: their eight distance loads are issued before any of the arithmetic
         const int nloc = i1 - i0;
@@ -1991,17 +2010,24 @@ namespace {
 
 int cost_matrix_impl(const char* fn, int32_t kind, const QpCircuit* circ, const double* D, int32_t C, const int32_t* tab,
                      int64_t B, const uint8_t* a, int32_t ldq, const int32_t* ops, const int32_t* n_ops, int32_t max_ops,
-                     const uint8_t* avail, const int32_t* n_avail, double* cost_out, void* stream_) {
+                     const uint8_t* avail, const int32_t* n_avail, double* cost_out, void* stream_,
+                     const int16_t* resolved = nullptr) {
     if (kind != QP_CM_HQA && kind != QP_CM_TRHQA && kind != QP_CM_GTRHQA) return qp::fail(QP_EINVAL, "%s: bad kind", fn);
-    if (!circ || !D || !a || !ops || !n_ops || !avail || !n_avail || !cost_out) return qp::fail(QP_EINVAL, "%s: null argument", fn);
+    if (!D || !n_ops || !avail || !n_avail || !cost_out) return qp::fail(QP_EINVAL, "%s: null argument", fn);
+    if (!resolved && (!circ || !a || !ops)) return qp::fail(QP_EINVAL, "%s: null argument", fn);
     if (B <= 0 || B > 65535) return qp::fail(QP_EINVAL, "%s: B must be 1..65535 per call", fn);
     if (max_ops <= 0) return qp::fail(QP_EINVAL, "%s: max_ops must be positive", fn);
     if (C <= 0 || C > 256) return qp::fail(QP_EINVAL, "%s: bad core count", fn);
-    if (!circ->edges || (kind != QP_CM_GTRHQA && !circ->lookahead)) return qp::fail(QP_EINVAL, "%s: circuit tables missing", fn);
-    if (ldq < circ->Q) return qp::fail(QP_EINVAL, "%s: ldq < Q", fn);
+    if (!resolved) {
+        if (!circ->edges || (kind != QP_CM_GTRHQA && !circ->lookahead)) return qp::fail(QP_EINVAL, "%s: circuit tables missing", fn);
+        if (ldq < circ->Q) return qp::fail(QP_EINVAL, "%s: ldq < Q", fn);
+    } else if (reinterpret_cast<uintptr_t>(resolved) % 16 != 0) {
+        return qp::fail(QP_EINVAL, "%s: resolved ops must be 16-byte aligned", fn);
+    }
     CmArgs p{};
-    p.edges = circ->edges;
-    p.lookahead = circ->lookahead;
+    p.resolved = resolved;
+    p.edges = circ ? circ->edges : nullptr;
+    p.lookahead = circ ? circ->lookahead : nullptr;
     p.D = D;
     p.tab = tab;
     p.t = nullptr;
@@ -2025,6 +2051,13 @@ int cost_matrix_impl(const char* fn, int32_t kind, const QpCircuit* circ, const 
 }
 
 }  // namespace
+
+int qp::cost_matrix_resolved(int32_t kind, const double* tables, int32_t C, const int32_t* tab_index, int64_t B,
+                             const int16_t* resolved, const int32_t* n_ops, int32_t max_ops, const uint8_t* avail,
+                             const int32_t* n_avail, double* cost_out, void* stream) {
+    return cost_matrix_impl("cost_matrix_resolved", kind, nullptr, tables, C, tab_index, B, nullptr, 0, nullptr, n_ops, max_ops,
+                            avail, n_avail, cost_out, stream, resolved);
+}
 
 extern "C" int qp_cost_matrix(int32_t kind, const QpCircuit* circ, const QpDTable* dt, int64_t B, const int32_t* t,
                               const uint8_t* a, int32_t ldq, const int32_t* ops, const int32_t* n_ops, int32_t max_ops,
