@@ -310,8 +310,9 @@ int qp_cost_matrix_multi(int32_t kind, const QpCircuit* circ, const double* tabl
  * of hqa_placer.place_per_timeslice (HQA_placer.py:56-176: per slice the gates whose qubits sit on different
  * cores, the while-loop with its iteration budget, make-space when no core has room (:180-204), the op x core
  * cost matrix (:112-122 with :208-241; TRHQA_placer.py:135-166 with :471-532), linear_sum_assignment (:126) and
- * the moves (:129-145)).  Cost matrices are computed on the device (the kernel of qp_cost_matrix); the
- * assignment solves stay on the host.  The batch is split over `lanes` host threads, each driving its instances
+ * the moves (:129-145)).  Cost matrices are computed on the device (the kernel of qp_cost_matrix, fed with the
+ * cores of every op's qubits and look-ahead partners as the host resolved them; circ->lookahead is copied to the
+ * host once per call); the assignment solves stay on the host.  The batch is split over `lanes` host threads, each driving its instances
  * through all slices on its own stream: streams[l] is the HIP stream of lane l (lanes of them, all on the current
  * device, none of them busy with work this call must wait for).
  * circ / dt: device tables as for qp_cost_matrix (dt QP_DT_F64).  slice_edge_ptr [T+1], edges [nE], D [C*C]:
