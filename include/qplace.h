@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define QP_VERSION 200
+#define QP_VERSION 201
 
 #define QP_OK 0
 #define QP_EINVAL (-1)   /* bad argument (shape, alignment, range) */
@@ -240,6 +240,16 @@ size_t qp_slice_cost_workspace(int32_t T, int64_t B);
  * (D[a][b] + D[b][a]) / 2 to the number of times the unordered pair {a, b} occurs. */
 int qp_slice_cost_v3(const QpCircuit* circ, const QpDTable* dt, const uint8_t* A, int64_t B, int32_t Tp,
                      int32_t ldq, double* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The same sum slice by slice: out[b][t - t_begin] (dev double [B][t_end - t_begin]) = what timeslice t adds in
+ * hqa_placer.per_timeslice_cost (HQA_placer.py:259-287: its crossing gates, :266-274, and from slice 2 on the
+ * qubits that are on another core than in slice t - 1, :277-285), for t_begin <= t < t_end.  The rows of A may be
+ * a window of the circuit: row r of a partition is the assignment of slice row0 + r, and the window must hold rows
+ * t_begin - 1 (from slice 2 on) to t_end - 1.  A long circuit is costed in contiguous pieces this way, one per
+ * GPU, with one row shared between neighbours; the pieces' sums add up to qp_slice_cost_v3's value to rounding.
+ * Entries are read from dt->table (either kind); needs no workspace. */
+int qp_slice_cost_v3_slices(const QpCircuit* circ, const QpDTable* dt, const uint8_t* A, int64_t B, int32_t Tp,
+                            int32_t ldq, int32_t row0, int32_t t_begin, int32_t t_end, double* out, void* stream);
 
 /* qp_slice_cost_v3 with one distance table per partition: tables is dev double [S][C*C] (row = source core,
  * zero diagonal, entries may be +inf), partition b is costed with table tab_index[b] (dev int32 [B], values

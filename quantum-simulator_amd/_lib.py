@@ -104,6 +104,8 @@ EXPORTS = {
     "qp_cost_matrix_multi": (C.c_int, [C.c_int32, C.POINTER(QpCircuit), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                        C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p]),
+    "qp_slice_cost_v3_slices": (C.c_int, [C.POINTER(QpCircuit), C.POINTER(QpDTable), C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                          C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "qp_slice_cost_v3_multi": (C.c_int, [C.POINTER(QpCircuit), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                          C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "qp_apsp_f64_batch": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,

@@ -2079,6 +2079,100 @@ extern "C" int qp_cost_matrix_multi(int32_t kind, const QpCircuit* circ, const d
 }
 
 // ------------------------------------------------------------------------------------------------
+// Cost V3 slice by slice: out[b][t - t_begin] = the terms timeslice t adds to the sum of HQA_placer.py:259-287
+// (its crossing gates; from slice 2 on the qubits that changed core since slice t - 1).  One wave per
+// (slice, partition); the partition rows may be a window of the circuit's slices that starts at slice row0, so
+// a long circuit can be costed in contiguous pieces (one per GPU) that only share the row before each piece.
+// ------------------------------------------------------------------------------------------------
+
+namespace {
+
+struct V3SliceArgs {
+    const uint8_t* A;
+    const int32_t* sep;
+    const QpEdge* edges;
+    const void* table;
+    double* out;
+    int64_t B;
+    int32_t Tp, ldq, Q, C, row0, t_begin, t_end;
+};
+
+template <int KIND>
+__global__ __launch_bounds__(256) void k_cost_v3_slices(V3SliceArgs p) {
+    using E = typename Tab<KIND>::elem;
+    const E* tab = static_cast<const E*>(p.table);
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int nt = p.t_end - p.t_begin;
+    const int64_t items = (int64_t)nt * p.B;
+    const int C = p.C;
+    for (int64_t it = (int64_t)blockIdx.x * 4 + wave; it < items; it += (int64_t)gridDim.x * 4) {
+        const int t = p.t_begin + (int)(it / p.B);  // consecutive waves share the slice's gates
+        const int64_t b = it % p.B;
+        const uint8_t* cur = p.A + ((size_t)b * p.Tp + (t - p.row0)) * p.ldq;
+        double acc = 0.0;
+        for (int e = p.sep[t] + lane; e < p.sep[t + 1]; e += kWave) {
+            const QpEdge ed = p.edges[e];
+            const int au = min((int)cur[ed.u], C - 1), av = min((int)cur[ed.v], C - 1);
+            if (au != av) acc += (double)tab[au * C + av];
+        }
+        if (t >= 2) {  // movement is charged from slice 2 on
+            const uint8_t* prv = cur - p.ldq;
+            for (int k = lane * 16; k < p.ldq; k += kWave * 16) {
+                const uint4 c4 = *reinterpret_cast<const uint4*>(cur + k), p4 = *reinterpret_cast<const uint4*>(prv + k);
+                const uint32_t cw[4] = {c4.x, c4.y, c4.z, c4.w}, pw[4] = {p4.x, p4.y, p4.z, p4.w};
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    if (cw[w] == pw[w]) continue;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int from = min((int)((pw[w] >> (8 * j)) & 0xFFu), C - 1), to = min((int)((cw[w] >> (8 * j)) & 0xFFu), C - 1);
+                        if (k + 4 * w + j < p.Q && from != to) acc += (double)tab[from * C + to];
+                    }
+                }
+            }
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) p.out[(size_t)b * nt + (t - p.t_begin)] = acc;
+    }
+}
+
+}  // namespace
+
+extern "C" int qp_slice_cost_v3_slices(const QpCircuit* circ, const QpDTable* dt, const uint8_t* A, int64_t B, int32_t Tp,
+                                       int32_t ldq, int32_t row0, int32_t t_begin, int32_t t_end, double* out, void* stream_) {
+    if (int rc = check_common("qp_slice_cost_v3_slices", circ, dt, A, B, Tp, ldq, out)) return rc;
+    const int32_t T = circ->T;
+    if (t_begin < 0 || t_end > T || t_begin > t_end) return qp::fail(QP_EINVAL, "qp_slice_cost_v3_slices: slices %d..%d of %d", t_begin, t_end, T);
+    if (t_begin == t_end) return QP_OK;
+    // the window must hold every row the slices read: rows t_begin .. t_end - 1, and row t_begin - 1 from slice 2 on
+    const int32_t first = t_begin >= 2 ? t_begin - 1 : t_begin;
+    if (row0 < 0 || row0 > first || (int64_t)row0 + Tp < t_end)
+        return qp::fail(QP_EINVAL, "qp_slice_cost_v3_slices: rows %d..%d do not cover slices %d..%d", row0, row0 + Tp, first, t_end);
+    if (!circ->slice_edge_ptr || (circ->nE > 0 && !circ->edges)) return qp::fail(QP_EINVAL, "qp_slice_cost_v3_slices: circuit edge tables missing");
+    V3SliceArgs p{};
+    p.A = A;
+    p.sep = circ->slice_edge_ptr;
+    p.edges = circ->edges;
+    p.table = dt->table;
+    p.out = out;
+    p.B = B;
+    p.Tp = Tp;
+    p.ldq = ldq;
+    p.Q = circ->Q;
+    p.C = dt->C;
+    p.row0 = row0;
+    p.t_begin = t_begin;
+    p.t_end = t_end;
+    const int64_t items = (int64_t)(t_end - t_begin) * B;
+    const unsigned grid = (unsigned)std::min<int64_t>((int64_t)qp::device_cus() * 8, (items + 3) / 4);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (dt->kind == QP_DT_F64) k_cost_v3_slices<QP_DT_F64><<<grid, 256, 0, stream>>>(p);
+    else k_cost_v3_slices<QP_DT_U16><<<grid, 256, 0, stream>>>(p);
+    HIP_TRY(hipGetLastError());
+    return QP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Cost V3 with one distance table per instance (many damaged copies of one network)
 // ------------------------------------------------------------------------------------------------
 

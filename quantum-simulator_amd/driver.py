@@ -144,6 +144,30 @@ def reduce_table(local: np.ndarray, local_min: np.ndarray, device=None):
     return s.cpu().numpy(), m.cpu().numpy()
 
 
+def slice_shard(T: int, rank: int, world: int):
+    """Contiguous piece of the timeslices 0..T-1 for ``rank`` of ``world``: (t_begin, t_end, row0), where
+    row0 is the first partition row the piece reads (the row before the piece from slice 2 on: the movement
+    term of HQA_placer.py:277-285 compares a slice with the one before it)."""
+    t_begin, t_end = T * rank // world, T * (rank + 1) // world
+    return t_begin, t_end, (t_begin - 1 if t_begin >= 2 else t_begin)
+
+
+def sharded_cost_v3(engine, dc, dt, rows, table="packed"):
+    """HQA-family cost of partitions too long for one GPU's turn: every rank holds ``rows``, the uint8
+    [B, t_end - row0, ldq] window of its slice_shard of the circuit, costs its own slices and one SUM
+    all-reduce of B doubles adds the pieces (identity when not distributed).  Returns float64 [B]."""
+    dist = _dist()
+    rank = dist.get_rank() if dist else 0
+    world = dist.get_world_size() if dist else 1
+    t_begin, t_end, row0 = slice_shard(dc.ir.T, rank, world)
+    part = engine.cost_v3_slices(dc, dt, rows, t_begin, t_end, row0, table=table).sum(dim=1)
+    if dist is not None and world > 1:
+        if dist.get_backend() != "nccl":
+            part = part.cpu()
+        dist.all_reduce(part, op=dist.ReduceOp.SUM)
+    return part
+
+
 def run_simulation(cfg, device=None, verbose=True):
     from ._lib import QplaceError
     from .circuit import circuit_from_qasm

@@ -227,6 +227,23 @@ class Engine:
                                          ws.data_ptr(), ws.numel(), _stream_ptr(self.device)))
         return out
 
+    def cost_v3_slices(self, dc: DeviceCircuit, dt: DistanceTable, A, t_begin=0, t_end=None, row0=0, out=None, table="packed"):
+        """What each timeslice t_begin <= t < t_end adds to the HQA-family cost: float64 [B, t_end - t_begin].
+        Row r of a partition in ``A`` is the assignment of slice ``row0 + r`` (a window of the circuit is enough:
+        it must hold row t_begin - 1, from slice 2 on, to row t_end - 1)."""
+        torch = _torch()
+        B, Tp, ldq = self._check_partitions(dc, A)
+        t_end = dc.ir.T if t_end is None else t_end
+        if out is None:
+            out = torch.empty((B, max(t_end - t_begin, 0)), dtype=torch.float64, device=self.device)
+        if t_end <= t_begin:
+            return out
+        tab = {"packed": dt.packed, "table": dt.table_only, "f64": dt.f64}[table]
+        with self._on_device():
+            check(lib().qp_slice_cost_v3_slices(C.byref(dc.c), C.byref(tab), A.data_ptr(), B, Tp, ldq, row0, t_begin, t_end,
+                                                out.data_ptr(), _stream_ptr(self.device)))
+        return out
+
     def cost_v3_multi(self, dc: DeviceCircuit, tables, tab_index, A, out=None):
         """HQA-family cost of B dense partitions, partition b with the distance table ``tables[tab_index[b]]``:
         ``tables`` float64 [S, C, C] and ``tab_index`` int32 [B] on the device (zero diagonals, inf allowed)."""

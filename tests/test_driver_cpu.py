@@ -247,3 +247,17 @@ def test_two_ranks_without_a_seed_build_the_same_machine(tmp_path):
     assert outs[0][0] == outs[1][0], "edge weights differ between ranks"
     assert len(set(outs[0][0])) > 1
     assert outs[0][1:] == outs[1][1:] and outs[0][1] == outs[0][2]
+
+
+def test_slice_shards_tile_the_circuit():
+    """Contiguous pieces that cover every timeslice once; each piece's window starts one row early from slice 2 on."""
+    from quantum_simulator_amd.driver import slice_shard
+    for T in (0, 1, 2, 3, 7, 1000):
+        for world in (1, 2, 3, 8):
+            seen = []
+            for rank in range(world):
+                t0, t1, row0 = slice_shard(T, rank, world)
+                assert 0 <= t0 <= t1 <= T
+                assert row0 == (t0 - 1 if t0 >= 2 else t0)
+                seen += list(range(t0, t1))
+            assert seen == list(range(T))

@@ -177,6 +177,52 @@ def test_cost_v3_four_partitions_per_wave(gpu, Q, T, C, B, integer):
         assert _close(got[b], want, integer), (b, got[b], want)
 
 
+@pytest.mark.parametrize("Q,T,C,B,integer", [(100, 21, 100, 3, False), (600, 40, 64, 3, True), (1500, 7, 256, 2, False),
+                                             (17, 2, 8, 2, True), (5, 1, 4, 2, False)])
+def test_cost_v3_slice_by_slice_and_in_windows(gpu, Q, T, C, B, integer):
+    """Per-slice terms against the oracle's sum over one slice at a time; their total against the batch kernel;
+    and the circuit costed in three contiguous pieces, each from a window of rows that starts one row before the
+    piece (what a rank of a multi-GPU job holds): the pieces reproduce the per-slice values bit for bit."""
+    from quantum_simulator_amd.driver import slice_shard
+    torch, engine, eng, dev = gpu
+    ir, eu, ev, w, rng = _random_setup(Q, T, C, integer, seed=Q * 3 + T)
+    D = engine.apsp(C, eu, ev, w)
+    dc, dt = engine.DeviceCircuit(ir, dev), engine.DistanceTable(D, dev)
+    T = ir.T
+    A = np.empty((B, T, dc.ldq), np.uint8)
+    A[:, 0] = rng.integers(0, C, size=(B, dc.ldq), dtype=np.uint8)
+    for t in range(1, T):
+        move = rng.random((B, dc.ldq)) < 0.3
+        A[:, t] = np.where(move, rng.integers(0, C, size=(B, dc.ldq), dtype=np.uint8), A[:, t - 1])
+    Ad = torch.from_numpy(A).to(dev)
+    got = eng.cost_v3_slices(dc, dt, Ad).cpu().numpy()
+    assert got.shape == (B, T)
+    Dl = D.tolist()
+    for b in range(B):
+        rows = A[b, :, :Q].tolist()
+        for t in range(T):
+            want = 0
+            for g in ir.slices[t]:
+                qs = ir.gate_q[g]
+                if len(qs) == 2 and not ir.gate_mr[g] and rows[t][qs[0]] != rows[t][qs[1]]:
+                    want += Dl[rows[t][qs[0]]][rows[t][qs[1]]]
+            if t >= 2:
+                want += sum(Dl[rows[t - 1][q]][rows[t][q]] for q in range(Q) if rows[t][q] != rows[t - 1][q])
+            assert _close(got[b, t], want, integer), (b, t, got[b, t], want)
+    total = eng.cost_v3(dc, dt, Ad).cpu().numpy()
+    for b in range(B):
+        assert _close(got[b].sum(), total[b], integer), (b, got[b].sum(), total[b])
+    pieces = []
+    for rank in range(3):
+        t0, t1, row0 = slice_shard(T, rank, 3)
+        window = torch.from_numpy(np.ascontiguousarray(A[:, row0:max(t1, row0 + 1)])).to(dev)
+        pieces.append(eng.cost_v3_slices(dc, dt, window, t0, t1, row0).cpu().numpy())
+    assert np.concatenate(pieces, axis=1).tobytes() == got.tobytes()
+    from quantum_simulator_amd._lib import QplaceError
+    with pytest.raises(QplaceError):
+        eng.cost_v3_slices(dc, dt, Ad[:, :T - 1].contiguous() if T > 1 else Ad, 0, T + (T == 1), 0)  # a window that is one row short
+
+
 PAIR_SHAPES = [  # Q, T, C, B, chord edges dropped so the graph falls apart, moves per row
     (1024, 40, 256, 3, False, 0.3), (600, 70, 200, 2, False, 0.05), (1021, 5, 140, 2, False, 1.0),
     (700, 33, 256, 2, True, 0.3), (1024, 130, 255, 5, False, 0.02),
