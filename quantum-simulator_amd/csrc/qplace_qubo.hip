@@ -627,10 +627,11 @@ __device__ inline uint32_t mix32(uint64_t z) {
     return (uint32_t)(z ^ (z >> 32)) | 1u;
 }
 
-__device__ inline bool metropolis(int dE, float beta, uint32_t& rng) {
+// beta2 = -beta * log2(e): accept with probability exp(-beta dE) = 2^(beta2 dE)
+__device__ inline bool metropolis(int dE, float beta2, uint32_t& rng) {
     if (dE <= 0) return true;
     const float u = (float)(rng_next(rng) >> 8) * (1.0f / 16777216.0f);
-    return u < __expf(-beta * (float)dE);
+    return u < __builtin_amdgcn_exp2f(beta2 * (float)dE);
 }
 
 __global__ __launch_bounds__(256) void k_qubo_anneal(SaArgs p) {
@@ -697,7 +698,8 @@ __global__ __launch_bounds__(256) void k_qubo_anneal(SaArgs p) {
     const bool lane_used = ls < S;
     int dEsum = 0;
     for (int sweep = 0; sweep < p.sweeps; ++sweep) {
-        const float beta = p.beta_hot * __expf(p.beta_ratio_log * (p.sweeps > 1 ? (float)sweep / (float)(p.sweeps - 1) : 0.0f));
+        const float beta = -1.44269504088896f * p.beta_hot *
+                           __expf(p.beta_ratio_log * (p.sweeps > 1 ? (float)sweep / (float)(p.sweeps - 1) : 0.0f));  // times -log2(e)
         for (int par = 0; par < 2; ++par) {
             const int nsl = (T - par + 1) / 2;  // slices of this parity
             for (int b0 = 0; b0 < nsl; b0 += S) {
@@ -746,13 +748,16 @@ __global__ __launch_bounds__(256) void k_qubo_anneal(SaArgs p) {
                                 o1 &= o1 - 1;
                             }
                             while (o2) {
-                                mv += hcol[__builtin_ctz(o2) * C];
+                                mv += hcol[__mul24(__builtin_ctz(o2), C)];
                                 o2 &= o2 - 1;
                             }
                             const int bit = (w >> lj) & 1u;
                             const int d = 1 - 2 * bit;
                             const int Ai = __popc(w);
-                            const int dE = 4 * d * (2 * (Ai - 1) + d) + 4 * d * (2 * L + d) + 10 * d * (lap + mv);
+                            // 4 d (2 (Ai - 1) + d) + 4 d (2 L + d) + 10 d (lap + mv) with d = +-1 (d d = 1), without a
+                            // full 32-bit multiply: 8 + d (8 (Ai - 1 + L) + 10 (lap + mv))
+                            const int sl = ((Ai - 1 + L) << 3) + __mul24(10, lap + mv);
+                            const int dE = 8 + (bit ? -sl : sl);
                             if (metropolis(dE, beta, rng)) {
                                 mk[i] = w ^ (1u << lj);
                                 L += d;
@@ -765,7 +770,7 @@ __global__ __launch_bounds__(256) void k_qubo_anneal(SaArgs p) {
                     for (int q = 0; q < cap; ++q) {
                         const int bit = (y >> q) & 1u;
                         const int d = 1 - 2 * bit;
-                        const int dE = 4 * d * (-2 * L + d);
+                        const int dE = 4 - (bit ? -8 * L : 8 * L);  // 4 d (-2 L + d)
                         if (metropolis(dE, beta, rng)) {
                             y ^= 1u << q;
                             L -= d;
