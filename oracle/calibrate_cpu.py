@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """TEST INFRASTRUCTURE ONLY — times the CPU restatement (oracle/placer_oracle.py, precomputed distance
 matrix) on golden cases, so that CPU numbers measured on a GPU box can be related to the reference's own
-Dijkstra-per-look-up timings recorded in BASELINE.md.  Prints one line per (case, placer)."""
+Dijkstra-per-look-up timings, which were taken once in the container that holds the reference.  Prints one line
+per (case, placer)."""
 import os
 import sys
 import time
