@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define QP_VERSION 201
+#define QP_VERSION 202
 
 #define QP_OK 0
 #define QP_EINVAL (-1)   /* bad argument (shape, alignment, range) */
@@ -64,7 +64,7 @@ typedef struct QpCircuit {
     int32_t nE; /* counted two-qubit gates */
     int32_t nV; /* visits */
     int32_t max_slice_edges; /* most counted gates in one slice; 0 = not given (Q/2 is assumed) */
-    int32_t reserved_;
+    int32_t group_ldq;       /* row pitch group_sched was laid out for; 0 = no grouped gate list */
     const int32_t* slice_edge_ptr;  /* [T+1] CSR over edges */
     const QpEdge* edges;            /* [nE] */
     const int16_t* lookahead;       /* [nE*6] other-qubit of the <=2 two-qubit commands that touch
@@ -77,6 +77,12 @@ typedef struct QpCircuit {
                                        QP_SCHED_CHUNK, QP_SCHED_TAIL zero words after the last slice); the dense
                                        cost kernels for long rows read this list */
     const int32_t* sched_ptr;       /* [T+1] start of every slice in edges_sched (required with it) */
+    const uint32_t* group_sched;    /* optional, rows of at most 512 bytes: the same gates in the layout
+                                       qp_schedule_gate_groups writes for the row pitch group_ldq (the gates of
+                                       qp_group_rows(group_ldq) consecutive slices together, endpoints as byte offsets
+                                       into those rows, padded like edges_sched); the dense cost kernels for short
+                                       rows read this list when the partitions' row pitch equals group_ldq */
+    const int32_t* group_ptr;       /* [ceil(T / qp_group_rows(group_ldq)) + 1] start of every group (required with it) */
 } QpCircuit;
 
 /* Distance table as the kernels consume it. */
@@ -179,6 +185,19 @@ int qp_qasm_scan(const char* text, int64_t n, int64_t start, int32_t n_regs, con
 #define QP_SCHED_TAIL 512
 int qp_schedule_gates(int32_t T, const int32_t* slice_edge_ptr, const uint16_t* eu, const uint16_t* ev,
                       int32_t* sched_ptr_out /* [T+1] */, uint32_t* sched_out, int64_t sched_capacity);
+
+/* Rows of at most 512 bytes: a wave of the dense cost kernels takes G = qp_group_rows(ldq) = 64 / (ldq / 16)
+ * consecutive slices per step (64 lanes x 16 bytes of rows), slices j*G .. j*G + G - 1 forming group j.
+ * qp_schedule_gate_groups lays the counted gates out group by group for QpCircuit.group_sched / group_ptr: words
+ * a | b << 16 with a = (t - j*G) * ldq + u and b = (t - j*G) * ldq + v, the byte offsets of the gate's two qubits
+ * in the group's rows, every group padded with zero words to a multiple of QP_SCHED_CHUNK, QP_SCHED_TAIL zero
+ * words at the end, runs of 32 gates spread over LDS banks as in qp_schedule_gates.  sched_capacity (words)
+ * must be at least sum_j roundup(E_j, QP_SCHED_CHUNK) + QP_SCHED_TAIL.  qp_group_rows returns 0 for a row pitch
+ * that is not a multiple of 16 in 16..512.  No reference counterpart. */
+int32_t qp_group_rows(int32_t ldq);
+int qp_schedule_gate_groups(int32_t T, const int32_t* slice_edge_ptr, const uint16_t* eu, const uint16_t* ev,
+                            int32_t ldq, int32_t* group_ptr_out /* [ceil(T/G)+1] */, uint32_t* sched_out,
+                            int64_t sched_capacity);
 
 /* Chooses the device representation of a host distance matrix and writes it into a host staging
  * buffer the caller then copies to the device (C*C*8 bytes is always enough).  The diagonal is

@@ -21,9 +21,10 @@ QP_SCHED_CHUNK, QP_SCHED_TAIL = 64, 512
 
 class QpCircuit(C.Structure):
     _fields_ = [("Q", C.c_int32), ("T", C.c_int32), ("nE", C.c_int32), ("nV", C.c_int32),
-                ("max_slice_edges", C.c_int32), ("reserved_", C.c_int32),
+                ("max_slice_edges", C.c_int32), ("group_ldq", C.c_int32),
                 ("slice_edge_ptr", C.c_void_p), ("edges", C.c_void_p), ("lookahead", C.c_void_p),
-                ("slice_visit_ptr", C.c_void_p), ("visits", C.c_void_p), ("edges_sched", C.c_void_p), ("sched_ptr", C.c_void_p)]
+                ("slice_visit_ptr", C.c_void_p), ("visits", C.c_void_p), ("edges_sched", C.c_void_p), ("sched_ptr", C.c_void_p),
+                ("group_sched", C.c_void_p), ("group_ptr", C.c_void_p)]
 
 
 class QpGridMetric(C.Structure):
@@ -74,6 +75,9 @@ EXPORTS = {
                                C.POINTER(C.c_int64)]),
     "qp_schedule_gates": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_int64]),
+    "qp_group_rows": (C.c_int32, [C.c_int32]),
+    "qp_schedule_gate_groups": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                          C.c_int64]),
     "qp_dtable_pack": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.POINTER(C.c_int32),
                                  C.POINTER(C.c_size_t)]),
     "qp_dtable_grid_metric": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(QpGridMetric)]),

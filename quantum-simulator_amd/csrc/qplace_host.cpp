@@ -12,6 +12,7 @@
 #include <limits>
 #include <queue>
 #include <thread>
+#include <utility>
 #include <vector>
 
 namespace qp {
@@ -543,6 +544,54 @@ extern "C" int qp_timeslices(int32_t n_gates, const int32_t* gq0, const int32_t*
     return QP_OK;
 }
 
+namespace {
+
+// Writes the (first, second) endpoint pairs of one bucket of gates (a slice, or a group of slices) as words
+// first | second << 16, ordered so that runs of 32 consecutive gates (the lanes that share LDS cycles) have their
+// endpoints in different 4-byte LDS banks where possible.  Returns the number of words written (= pairs.size()).
+int32_t spread_over_banks(const std::vector<std::pair<uint16_t, uint16_t>>& pairs, uint32_t* out) {
+    std::vector<int32_t> pool(pairs.size()), rest, group;
+    for (size_t k = 0; k < pairs.size(); ++k) pool[k] = (int32_t)k;
+    int32_t w = 0;
+    while (!pool.empty()) {
+        uint32_t used_u = 0, used_v = 0;
+        group.clear();
+        rest.clear();
+        for (int32_t e : pool) {  // gates whose two endpoints fall into LDS banks nobody in the group uses
+            const uint32_t mu = 1u << ((pairs[e].first >> 2) & 31), mv = 1u << ((pairs[e].second >> 2) & 31);
+            if (group.size() < 32 && !(used_u & mu) && !(used_v & mv)) {
+                group.push_back(e);
+                used_u |= mu;
+                used_v |= mv;
+            } else {
+                rest.push_back(e);
+            }
+        }
+        if (group.size() < 32 && !rest.empty()) {  // then gates that clash in one endpoint only, then any
+            pool.clear();
+            for (int32_t e : rest) {
+                const uint32_t mu = 1u << ((pairs[e].first >> 2) & 31);
+                if (group.size() < 32 && !(used_u & mu)) {
+                    group.push_back(e);
+                    used_u |= mu;
+                } else {
+                    pool.push_back(e);
+                }
+            }
+            rest.clear();
+            for (int32_t e : pool) {
+                if (group.size() < 32) group.push_back(e);
+                else rest.push_back(e);
+            }
+        }
+        for (int32_t e : group) out[w++] = (uint32_t)pairs[e].first | ((uint32_t)pairs[e].second << 16);
+        pool.swap(rest);
+    }
+    return w;
+}
+
+}  // namespace
+
 extern "C" int qp_schedule_gates(int32_t T, const int32_t* slice_edge_ptr, const uint16_t* eu, const uint16_t* ev,
                                  int32_t* sched_ptr_out, uint32_t* sched_out, int64_t sched_capacity) {
     if (T < 0 || !slice_edge_ptr || !sched_ptr_out || !sched_out || (slice_edge_ptr[T] > 0 && (!eu || !ev)))
@@ -554,47 +603,53 @@ extern "C" int qp_schedule_gates(int32_t T, const int32_t* slice_edge_ptr, const
         return qp::fail(QP_ENOSPC, "qp_schedule_gates: needs room for %lld words", (long long)need);
     std::fill(sched_out, sched_out + need, 0u);
     sched_ptr_out[0] = 0;
-    std::vector<int32_t> pool, rest, group;
+    std::vector<std::pair<uint16_t, uint16_t>> pairs;
     for (int32_t t = 0; t < T; ++t) {
         const int32_t a = slice_edge_ptr[t], b = slice_edge_ptr[t + 1];
-        pool.clear();
-        for (int32_t e = a; e < b; ++e) pool.push_back(e);
-        int32_t w = sched_ptr_out[t];
+        pairs.clear();
+        for (int32_t e = a; e < b; ++e) pairs.emplace_back(eu[e], ev[e]);
+        const int32_t w = sched_ptr_out[t];
         sched_ptr_out[t + 1] = w + (b - a + QP_SCHED_CHUNK - 1) / QP_SCHED_CHUNK * QP_SCHED_CHUNK;
-        while (!pool.empty()) {
-            uint32_t used_u = 0, used_v = 0;
-            group.clear();
-            rest.clear();
-            for (int32_t e : pool) {  // gates whose two endpoints fall into LDS banks nobody in the group uses
-                const uint32_t mu = 1u << ((eu[e] >> 2) & 31), mv = 1u << ((ev[e] >> 2) & 31);
-                if (group.size() < 32 && !(used_u & mu) && !(used_v & mv)) {
-                    group.push_back(e);
-                    used_u |= mu;
-                    used_v |= mv;
-                } else {
-                    rest.push_back(e);
-                }
+        spread_over_banks(pairs, sched_out + w);
+    }
+    return QP_OK;
+}
+
+extern "C" int32_t qp_group_rows(int32_t ldq) {
+    if (ldq < 16 || ldq > 512 || ldq % 16 != 0) return 0;
+    return 64 / (ldq / 16);
+}
+
+extern "C" int qp_schedule_gate_groups(int32_t T, const int32_t* slice_edge_ptr, const uint16_t* eu, const uint16_t* ev,
+                                       int32_t ldq, int32_t* group_ptr_out, uint32_t* sched_out, int64_t sched_capacity) {
+    const int32_t G = qp_group_rows(ldq);
+    if (T < 0 || G == 0 || !slice_edge_ptr || !group_ptr_out || !sched_out || (slice_edge_ptr[T] > 0 && (!eu || !ev)))
+        return qp::fail(QP_EINVAL, "qp_schedule_gate_groups: bad argument (rows of 16 to 512 bytes, a multiple of 16)");
+    const int32_t NG = (T + G - 1) / G;
+    int64_t need = QP_SCHED_TAIL;
+    for (int32_t j = 0; j < NG; ++j) {
+        const int32_t a = slice_edge_ptr[j * G], b = slice_edge_ptr[std::min(T, (j + 1) * G)];
+        need += (int64_t)(b - a + QP_SCHED_CHUNK - 1) / QP_SCHED_CHUNK * QP_SCHED_CHUNK;
+    }
+    if (sched_capacity < need || need > std::numeric_limits<int32_t>::max())
+        return qp::fail(QP_ENOSPC, "qp_schedule_gate_groups: needs room for %lld words", (long long)need);
+    std::fill(sched_out, sched_out + need, 0u);
+    group_ptr_out[0] = 0;
+    std::vector<std::pair<uint16_t, uint16_t>> pairs;
+    for (int32_t j = 0; j < NG; ++j) {
+        const int32_t t0 = j * G, t1 = std::min(T, t0 + G);
+        pairs.clear();
+        for (int32_t t = t0; t < t1; ++t) {
+            const int32_t off = (t - t0) * ldq;  // the slice's row inside the group's strip
+            for (int32_t e = slice_edge_ptr[t]; e < slice_edge_ptr[t + 1]; ++e) {
+                if (eu[e] >= ldq || ev[e] >= ldq)
+                    return qp::fail(QP_EINVAL, "qp_schedule_gate_groups: gate %d names a qubit beyond the row pitch %d", e, ldq);
+                pairs.emplace_back((uint16_t)(off + eu[e]), (uint16_t)(off + ev[e]));
             }
-            if (group.size() < 32 && !rest.empty()) {  // then gates that clash in one endpoint only, then any
-                pool.clear();
-                for (int32_t e : rest) {
-                    const uint32_t mu = 1u << ((eu[e] >> 2) & 31);
-                    if (group.size() < 32 && !(used_u & mu)) {
-                        group.push_back(e);
-                        used_u |= mu;
-                    } else {
-                        pool.push_back(e);
-                    }
-                }
-                rest.clear();
-                for (int32_t e : pool) {
-                    if (group.size() < 32) group.push_back(e);
-                    else rest.push_back(e);
-                }
-            }
-            for (int32_t e : group) sched_out[w++] = (uint32_t)eu[e] | ((uint32_t)ev[e] << 16);
-            pool.swap(rest);
         }
+        const int32_t w = group_ptr_out[j];
+        group_ptr_out[j + 1] = w + ((int32_t)pairs.size() + QP_SCHED_CHUNK - 1) / QP_SCHED_CHUNK * QP_SCHED_CHUNK;
+        spread_over_banks(pairs, sched_out + w);
     }
     return QP_OK;
 }

@@ -121,6 +121,7 @@ constexpr int kTabGrid = 4;    // no table: the distance is a grid metric comput
 constexpr int kV3Threads = 1024;
 constexpr int kV3Waves = kV3Threads / kWave;
 constexpr int kV3Ahead = 4;  // row groups in flight per wave beyond the one being processed
+constexpr int kRowEdgeChunks = 4;  // 64-gate chunks of a row (or group of rows) that are loaded together with it
 
 struct V3Args {
     const uint8_t* A;
@@ -128,6 +129,8 @@ struct V3Args {
     const QpEdge* edges;
     const uint32_t* edges_sched;
     const int32_t* sptr;
+    const uint32_t* gsched;  // grouped gate list (rows of at most 512 bytes) and the start of every group in it
+    const int32_t* gptr;
     const void* table;
     double* partial;
     int64_t B, nitems;
@@ -306,13 +309,212 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3(V3Args p) {
     }
 }
 
+// Rows of at most 512 bytes with the grouped gate list (QpCircuit.group_sched).  As in k_cost_v3 a wave owns an
+// item and takes G = 64 / lpr rows per step, one 16-byte piece per lane, parked in a private LDS strip
+// [row before][G rows]; what differs is that nothing a step consumes is loaded inside the step.  Items are runs of
+// whole groups of G slices (group j = slices j*G .. j*G + G - 1 whatever the item), so the gates of a step are the
+// words of one group of the list: endpoints as byte offsets into the strip's G rows, padded to whole 64-gate
+// chunks with zero words (one byte with itself: distance zero).  The rows of step s + AHEAD and the first
+// kRowEdgeChunks chunks of its group are requested while step s is worked on, from addresses that depend on no
+// loaded value, so the waits the compiler counts leave the younger loads in flight.  Items are long (up to 256
+// steps; a whole partition when it is shorter) so that the start of an item, where the first rows are waited for
+// with nothing else to do, is a small part of it.  TABMODE: kTabLds256, kTabLdsC, kTabGlobal, or kTabGrid (no table;
+// WRAP = some dimension of the grid is a ring).
+template <int KIND, int TABMODE, bool WRAP, int AHEAD = kV3Ahead>
+__global__ __launch_bounds__(kV3Threads) void k_cost_v3_groups(V3Args p) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    using E = typename Tab<KIND>::elem;
+    using Acc = typename Tab<KIND>::acc;
+    static_assert(kRowEdgeChunks == 4, "four gate chunks fill one dword of endpoints");
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    uint32_t tab_off = 0;
+    const E* tab;
+    if constexpr (TABMODE == kTabLds256) {
+        tab_off = stage_table_pitch256<E>(smem, p.table, p.C);
+        tab = reinterpret_cast<const E*>(smem);
+    } else if constexpr (TABMODE == kTabLdsC) {
+        tab_off = stage_table(smem, p.table, p.table_bytes);
+        tab = reinterpret_cast<const E*>(smem);
+    } else {
+        tab = static_cast<const E*>(p.table);
+    }
+    const int ldq = p.ldq, G = p.G, lpr = p.lpr;
+    const uint32_t C = (uint32_t)p.C;
+    const uint32_t tbase = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_u8*)smem);
+    auto in_table = [&](uint32_t idx) -> uint32_t {
+        if constexpr (TABMODE == kTabGlobal) return min(idx, C * C - 1u);
+        else return idx;
+    };
+    uint8_t* strip = smem + tab_off + (size_t)wave * (G + 1) * ldq;  // [row before][G rows]
+    uint8_t* rows = strip + ldq;
+    const bool lane_on = lane < G * lpr;
+    const int lrow = lane_on ? lane / lpr : 0;
+    const int lq0 = lane_on ? (lane - lrow * lpr) * 16 : 0;
+    const int lane_off = lane_on ? lane * 16 : 0;  // = lrow * ldq + lq0: the lane's piece inside a group
+    const bool last_row = lane_on && lrow == G - 1;
+    const int nvalid_row = lane_on ? min(16, max(0, p.Q - lq0)) : 0;
+    uint32_t keep[4], kx[4], ky[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const int nb = min(4, max(0, nvalid_row - 4 * w));
+        keep[w] = nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u);
+        kx[w] = keep[w] & p.gxm;
+        ky[w] = keep[w] & p.gyi;
+    }
+    auto pair_at = [&](uint32_t from, uint32_t to) -> Acc {
+        if constexpr (TABMODE == kTabLds256) return tab[(from << 8) | to];
+        else return tab[in_table(__umul24(from, C) + to)];
+    };
+    auto four = [&](uint32_t pf, uint32_t cf) -> Acc {
+        if constexpr (TABMODE == kTabLds256) {
+            E e0, e1, e2, e3;
+            entries_at_halves<E>(__builtin_amdgcn_perm(pf, cf, 0x05010400u), tbase, e0, e1);
+            entries_at_halves<E>(__builtin_amdgcn_perm(pf, cf, 0x07030602u), tbase, e2, e3);
+            return ((Acc)e0 + (Acc)e1) + ((Acc)e2 + (Acc)e3);
+        } else {
+            Acc s = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s += (Acc)tab[in_table(__umul24((pf >> (8 * j)) & 0xFFu, C) + ((cf >> (8 * j)) & 0xFFu))];
+            return s;
+        }
+    };
+    const uint32_t* gsched_lane = p.gsched + lane;
+
+    for (int64_t it = (int64_t)blockIdx.x * kV3Waves + wave; it < p.nitems; it += (int64_t)gridDim.x * kV3Waves) {
+        const int chunk = (int)(it / p.B);
+        const int64_t b = it - (int64_t)chunk * p.B;
+        const int r0 = chunk * p.rows_per_item;  // a multiple of G
+        const int r1 = min(p.T, r0 + p.rows_per_item);
+        const int nsteps = (r1 - r0 + G - 1) / G;
+        const int j0 = r0 / G, jlast = j0 + nsteps - 1;
+        const uint8_t* base = p.A + (size_t)b * p.Tp * ldq;
+        Acc acc = 0;
+        uint32_t ax = 0, ay = 0;
+        GridAcc gacc;
+
+        // the lane's piece of step s: rows past the item's end repeat its last row (never counted)
+        auto fetch_rows = [&](int s) -> uint4 {
+            const int rowl = min(r0 + s * G + lrow, r1 - 1);
+            return load_row16(base + ((uint32_t)rowl * (uint32_t)ldq + (uint32_t)lq0));
+        };
+        auto fetch_gate = [&](int s, int c) -> uint32_t {
+            const uint32_t* gp = gsched_lane + p.gptr[min(j0 + s, jlast)];  // wave-uniform + lane
+            return gp[c * kWave];
+        };
+
+        if (r0 >= 1 && lane < lpr)
+            *reinterpret_cast<uint4*>(strip + lane * 16) =
+                *reinterpret_cast<const uint4*>(base + (size_t)(r0 - 1) * ldq + lane * 16);
+        uint4 ring[AHEAD];
+        uint32_t gring[AHEAD][kRowEdgeChunks];
+#pragma unroll
+        for (int k = 0; k < AHEAD; ++k) {
+            ring[k] = fetch_rows(k);
+#pragma unroll
+            for (int c = 0; c < kRowEdgeChunks; ++c) gring[k][c] = fetch_gate(k, c);
+        }
+
+        for (int s0 = 0; s0 < nsteps; s0 += AHEAD) {
+#pragma unroll
+            for (int k = 0; k < AHEAD; ++k) {
+                const int s = s0 + k;
+                if (s >= nsteps) break;
+                const uint4 cur = ring[k];
+                uint32_t gates[kRowEdgeChunks];
+#pragma unroll
+                for (int c = 0; c < kRowEdgeChunks; ++c) gates[c] = gring[k][c];
+                ring[k] = fetch_rows(s + AHEAD);
+#pragma unroll
+                for (int c = 0; c < kRowEdgeChunks; ++c) gring[k][c] = fetch_gate(s + AHEAD, c);
+
+                uint4 prv = make_uint4(0, 0, 0, 0);
+                if (lane_on) {
+                    *reinterpret_cast<uint4*>(rows + lane_off) = cur;
+                    prv = *reinterpret_cast<const uint4*>(strip + lane_off);  // the same piece one row earlier
+                }
+                const int w0 = p.gptr[j0 + s];
+                const int nch = (p.gptr[j0 + s + 1] - w0) / kWave;
+                uint32_t au[kRowEdgeChunks], av[kRowEdgeChunks];
+                if (nch >= kRowEdgeChunks) {
+#pragma unroll
+                    for (int c = 0; c < kRowEdgeChunks; ++c) {
+                        au[c] = rows[gates[c] & 0xFFFFu];
+                        av[c] = rows[gates[c] >> 16];
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < kRowEdgeChunks; ++c) {  // a chunk the group lacks: one byte twice
+                        const uint32_t g = c < nch ? gates[c] : 0u;
+                        au[c] = rows[g & 0xFFFFu];
+                        av[c] = rows[g >> 16];
+                    }
+                }
+                // movement: rows 2 .. r1 - 1, previous row -> this row; everything else compares a piece with itself
+                const int row = r0 + s * G + lrow;
+                const bool mv = row >= 2 && row < r1;
+                const uint32_t cw[4] = {cur.x, cur.y, cur.z, cur.w};
+                const uint32_t pw[4] = {mv ? prv.x : cur.x, mv ? prv.y : cur.y, mv ? prv.z : cur.z, mv ? prv.w : cur.w};
+                if constexpr (TABMODE == kTabGrid) {
+                    if constexpr (WRAP) {
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) gacc.add4(p, pw[w] & keep[w], cw[w] & keep[w]);
+                    } else {
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) {
+                            ax = __builtin_amdgcn_sad_u8(pw[w] & kx[w], cw[w] & kx[w], ax);
+                            ay = __builtin_amdgcn_sad_u8(pw[w] & ky[w], cw[w] & ky[w], ay);
+                        }
+                    }
+                    const uint32_t U = au[0] | au[1] << 8 | au[2] << 16 | au[3] << 24;
+                    const uint32_t V = av[0] | av[1] << 8 | av[2] << 16 | av[3] << 24;
+                    if constexpr (WRAP) {
+                        gacc.add4(p, U, V);
+                    } else {
+                        ax = __builtin_amdgcn_sad_u8(U & p.gxm, V & p.gxm, ax);
+                        ay = __builtin_amdgcn_sad_u8(U & p.gyi, V & p.gyi, ay);
+                    }
+                } else {
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {  // a lane skips four qubits that all stayed where they were
+                        const uint32_t pm = pw[w] & keep[w], cm = cw[w] & keep[w];
+                        if (pm != cm) acc += four(pm, cm);
+                    }
+                    Acc sg = 0;
+#pragma unroll
+                    for (int c = 0; c < kRowEdgeChunks; ++c) sg += pair_at(au[c], av[c]);
+                    acc += sg;
+                }
+                for (int c = kRowEdgeChunks; c < nch; ++c) {
+                    const uint32_t g = gsched_lane[w0 + c * kWave];
+                    const uint32_t U = rows[g & 0xFFFFu], V = rows[g >> 16];
+                    if constexpr (TABMODE != kTabGrid) {
+                        acc += pair_at(U, V);
+                    } else if constexpr (WRAP) {
+                        gacc.add4(p, U, V);
+                    } else {
+                        ax = __builtin_amdgcn_sad_u8(U & p.gxm, V & p.gxm, ax);
+                        ay = __builtin_amdgcn_sad_u8(U & p.gyi, V & p.gyi, ay);
+                    }
+                }
+                // the group's last row is "the row before" of the next step
+                if (last_row) *reinterpret_cast<uint4*>(strip + lq0) = cur;
+            }
+        }
+        double sum;
+        if constexpr (TABMODE != kTabGrid) sum = wave_sum(acc);
+        else if constexpr (WRAP) sum = gacc.total(p);
+        else sum = (double)p.gwx * wave_sum(ax) + (double)p.gwy * (wave_sum(ay) / (double)(1u << p.gxb));
+        if (lane == 0) p.partial[it] = sum;
+    }
+}
+
 // Rows longer than 512 bytes (one row per wave step).  Differences from k_cost_v3: the previous row
 // stays in registers (no LDS round trip), the LDS strip holds only the current row for the edge
 // endpoint gathers, and each row's first kRowEdgeChunks*64 gates are loaded together with the row,
 // kV3Ahead rows ahead, so that vector-memory results are consumed in the order they were requested.
 // Gates come from the scheduled list (u | v << 16, every slice padded to whole 64-gate chunks with
 // zero words, readable a few chunks past its end), so chunks are read and used without lane masks.
-constexpr int kRowEdgeChunks = 4;
 
 template <int KIND, int TABMODE, int AHEAD = kV3Ahead>
 __global__ __launch_bounds__(kV3Threads) void k_cost_v3_row(V3Args p) {
@@ -1693,6 +1895,8 @@ int slice_cost_v3_impl(const QpCircuit* circ, const QpDTable* dt, const uint8_t*
     p.edges = circ->edges;
     p.edges_sched = circ->edges_sched;
     p.sptr = circ->sched_ptr;
+    p.gsched = circ->group_sched;
+    p.gptr = circ->group_ptr;
     p.table = dt->table;
     p.B = B;
     p.T = T;
@@ -1741,6 +1945,49 @@ int slice_cost_v3_impl(const QpCircuit* circ, const QpDTable* dt, const uint8_t*
         return qp::fail(QP_ENOSPC, "qp_slice_cost_v3: workspace needs %zu bytes", (size_t)p.nitems * sizeof(double));
     p.partial = static_cast<double*>(workspace);
 
+    if (narrow && ldq <= 512 && circ->group_sched && circ->group_ptr && circ->group_ldq == ldq && circ->nE > 0) {
+        // rows of at most 512 bytes with the grouped gate list: whole groups of G slices per item, long items
+        V3Args q = p;
+        const int G = q.G;
+        const int64_t steps_total = (T + G - 1) / G;
+        const int64_t want = steps_total * B / ((int64_t)cus * kV3Waves * 4);
+        const int64_t spi = std::min<int64_t>(steps_total, std::min<int64_t>(256, std::max<int64_t>(8, want)));
+        q.rows_per_item = (int)(spi * G);
+        const int32_t gchunks = (T + q.rows_per_item - 1) / q.rows_per_item;
+        q.nitems = (int64_t)gchunks * B;
+        if (workspace_bytes >= (size_t)q.nitems * sizeof(double)) {
+            const bool gridpath = dt->kind == QP_DT_U16 && dt->grid.valid;
+            const size_t strips = (size_t)kV3Waves * (G + 1) * ldq;
+            const size_t tab256 = (size_t)dt->C * 256 * esz;
+            void (*kern)(V3Args) = nullptr;
+            size_t lds = strips;
+            if (gridpath) {
+                if (int rc = fill_grid_args(q, dt)) return rc;
+                kern = (dt->grid.wrap_x || dt->grid.wrap_y) ? k_cost_v3_groups<QP_DT_U16, kTabGrid, true>
+                                                            : k_cost_v3_groups<QP_DT_U16, kTabGrid, false>;
+            } else if (tab256 + strips <= (size_t)kLdsBytes) {
+                lds += tab256;
+                kern = dt->kind == QP_DT_F64 ? k_cost_v3_groups<QP_DT_F64, kTabLds256, false>
+                                             : k_cost_v3_groups<QP_DT_U16, kTabLds256, false>;
+            } else if (tab_padded + strips <= (size_t)kLdsBytes) {
+                lds += tab_padded;
+                kern = dt->kind == QP_DT_F64 ? k_cost_v3_groups<QP_DT_F64, kTabLdsC, false>
+                                             : k_cost_v3_groups<QP_DT_U16, kTabLdsC, false>;
+            } else {
+                kern = dt->kind == QP_DT_F64 ? k_cost_v3_groups<QP_DT_F64, kTabGlobal, false>
+                                             : k_cost_v3_groups<QP_DT_U16, kTabGlobal, false>;
+            }
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            int per_cu = 1;
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), kV3Threads, lds));
+            const unsigned ggrid = (unsigned)std::min<int64_t>((int64_t)cus * std::max(per_cu, 1), (q.nitems + kV3Waves - 1) / kV3Waves);
+            kern<<<ggrid, kV3Threads, lds, stream>>>(q);
+            HIP_TRY(hipGetLastError());
+            k_sum_chunks<<<(unsigned)((B + 255) / 256), 256, 0, stream>>>(q.partial, B, gchunks, out);
+            HIP_TRY(hipGetLastError());
+            return QP_OK;
+        }
+    }
     if (narrow) {
         const bool rowpath = ldq > 512 && circ->edges_sched != nullptr && circ->sched_ptr != nullptr && circ->nE > 0;
         const bool gridpath = dt->kind == QP_DT_U16 && dt->grid.valid;

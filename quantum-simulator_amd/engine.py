@@ -119,10 +119,18 @@ class DeviceCircuit:
         sptr, sched = ir.scheduled_edges()
         self._sched, self._sched_ptr = _to_dev(sched, self.device), _to_dev(sptr, self.device)
         most = int(np.diff(ir.slice_edge_ptr).max()) if ir.T else 0
-        self.c = QpCircuit(ir.Q, ir.T, ir.nE, ir.nV, most, 0, self._sep.data_ptr(), self._edges.data_ptr(),
-                           self._la.data_ptr(), self._svp.data_ptr(), self._visits.data_ptr(),
-                           self._sched.data_ptr(), self._sched_ptr.data_ptr())
         self.ldq = (ir.Q + 15) // 16 * 16
+        # rows of at most 512 bytes: the gates of the slices a wave takes per step, laid out together
+        grouped = ir.grouped_edges(self.ldq)
+        self._gsched = self._gptr = None
+        if grouped is not None:
+            self._gptr, self._gsched = _to_dev(grouped[0], self.device), _to_dev(grouped[1], self.device)
+        self.c = QpCircuit(ir.Q, ir.T, ir.nE, ir.nV, most, self.ldq if grouped is not None else 0,
+                           self._sep.data_ptr(), self._edges.data_ptr(),
+                           self._la.data_ptr(), self._svp.data_ptr(), self._visits.data_ptr(),
+                           self._sched.data_ptr(), self._sched_ptr.data_ptr(),
+                           self._gsched.data_ptr() if grouped is not None else None,
+                           self._gptr.data_ptr() if grouped is not None else None)
 
     @property
     def csr_bytes(self):

@@ -303,6 +303,27 @@ class CircuitIR:
                                                 _lib.ptr(sched), n))
         return sptr, sched
 
+    def grouped_edges(self, ldq: int):
+        """(group_ptr, words) for partitions with rows of ``ldq`` <= 512 bytes, or None when the rows are longer:
+        the counted gates of every ``64 // (ldq // 16)`` consecutive slices together, endpoints as byte offsets
+        into those rows (see qp_schedule_gate_groups)."""
+        from . import _lib
+        G = int(_lib.lib().qp_group_rows(int(ldq)))
+        if G == 0:
+            return None
+        eu = np.ascontiguousarray(self.edge_u, np.uint16)
+        ev = np.ascontiguousarray(self.edge_v, np.uint16)
+        sep = np.ascontiguousarray(self.slice_edge_ptr, np.int32)
+        ch = _lib.QP_SCHED_CHUNK
+        ng = (self.T + G - 1) // G
+        per_group = np.diff(sep.astype(np.int64)[np.minimum(np.arange(ng + 1) * G, self.T)])
+        n = int(((per_group + ch - 1) // ch * ch).sum()) + _lib.QP_SCHED_TAIL
+        sched = np.empty(n, np.uint32)
+        gptr = np.empty(ng + 1, np.int32)
+        _lib.check(_lib.lib().qp_schedule_gate_groups(self.T, _lib.ptr(sep), _lib.ptr(eu), _lib.ptr(ev), int(ldq),
+                                                      _lib.ptr(gptr), _lib.ptr(sched), n))
+        return gptr, sched
+
     # -- helpers ----------------------------------------------------------------------------------
     def slice_ops(self, t: int):
         """(edge index, u, v) of the counted gates of slice t, slice order."""

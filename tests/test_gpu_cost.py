@@ -142,6 +142,55 @@ def test_cost_v3_random(gpu, Q, T, C, B, integer):
         assert _close(got[b], want, integer), (b, got[b], want)
 
 
+SHORT_ROWS = [  # Q, T, C, B, integer weights, pmove: rows of 16 to 512 bytes (1 to 32 pieces, 64 to 2 rows per wave step)
+    (9, 700, 8, 5, True, 0.5), (30, 333, 16, 6, False, 0.3), (40, 6100, 20, 3, True, 0.2), (70, 150, 64, 9, False, 0.9),
+    (128, 77, 100, 4, False, 0.5), (130, 200, 256, 3, True, 0.5), (260, 1300, 200, 2, False, 0.1), (500, 64, 130, 5, False, 1.0),
+    (512, 3, 256, 4, True, 1.0), (18, 138, 16, 700, False, 0.3),
+]
+
+
+@pytest.mark.parametrize("Q,T,C,B,integer,pmove", SHORT_ROWS)
+def test_cost_v3_short_rows_in_groups(gpu, Q, T, C, B, integer, pmove):
+    """Rows of at most 512 bytes: a wave takes several slices per step and the gates come from the grouped list
+    (items of up to 256 steps, so the 6100-slice case has more than one item per partition); every table form
+    (16-bit and fp64 in LDS at either pitch, fp64 in device memory) against the vectorised CPU sum, and the same
+    partitions again for a caller that passes no grouped list."""
+    from oracle.cpu_variants import NumpyCost
+    torch, engine, eng, dev = gpu
+    ir, eu, ev, w, rng = _random_setup(Q, T, C, integer, seed=Q * 13 + T)
+    D = engine.apsp(C, eu, ev, w)
+    dc, dt = engine.DeviceCircuit(ir, dev), engine.DistanceTable(D, dev)
+    assert dc.ldq <= 512 and dc.c.group_ldq == dc.ldq and dc.c.group_sched
+    Tp = ir.T + (1 if Q % 2 else 0)
+    A = np.empty((B, Tp, dc.ldq), np.uint8)
+    A[:, 0] = rng.integers(0, C, size=(B, dc.ldq), dtype=np.uint8)
+    for t in range(1, Tp):
+        move = rng.random((B, dc.ldq)) < pmove
+        A[:, t] = np.where(move, rng.integers(0, C, size=(B, dc.ldq), dtype=np.uint8), A[:, t - 1])
+    A[:, :, Q:] = rng.integers(0, 256, size=(B, Tp, dc.ldq - Q), dtype=np.uint8)  # pad bytes are garbage
+    Ad = torch.from_numpy(A).to(dev)
+    got = eng.cost_v3(dc, dt, Ad).cpu().numpy()
+    assert got.tobytes() == eng.cost_v3(dc, dt, Ad).cpu().numpy().tobytes()
+    nc = NumpyCost(ir.slices, ir.gate_q, ir.gate_mr, D)
+    nterms = ir.nE + ir.T * Q
+    for b in range(min(B, 12)):
+        want = nc.cost(A[b, :ir.T, :Q])
+        assert _close(got[b], want, integer, nterms), (b, got[b], want)
+    saved = dc.c.group_sched, dc.c.group_ptr, dc.c.group_ldq
+    dc.c.group_sched, dc.c.group_ptr, dc.c.group_ldq = None, None, 0
+    try:
+        plain = eng.cost_v3(dc, dt, Ad).cpu().numpy()
+    finally:
+        dc.c.group_sched, dc.c.group_ptr, dc.c.group_ldq = saved
+    assert all(_close(plain[b], got[b], integer, nterms) for b in range(B)), (plain, got)
+    # a row pitch other than the one the list was laid out for: the list is not used
+    if dc.ldq + 16 <= 512:
+        wide = np.zeros((B, Tp, dc.ldq + 16), np.uint8)
+        wide[:, :, :dc.ldq] = A
+        again = eng.cost_v3(dc, dt, torch.from_numpy(wide).to(dev)).cpu().numpy()
+        assert all(_close(again[b], got[b], integer, nterms) for b in range(B)), (again, got)
+
+
 GROUPED = [  # Q, T, C, B, integer weights: rows over 512 bytes, table in LDS at pitch 256, 64 partitions or more
     (1000, 70, 256, 67, True), (1024, 9, 64, 64, False), (600, 41, 40, 130, False), (513, 3, 200, 65, True),
     (777, 2, 64, 66, False), (1024, 1, 256, 64, True),

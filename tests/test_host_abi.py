@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in qplace.h but not exported"
     assert declared == set(_lib.EXPORTS), "ctypes table and header disagree"
-    assert _lib.lib().qp_version() == 201
+    assert _lib.lib().qp_version() == 202
 
 
 @pytest.mark.parametrize("name", ALL_CASES)
@@ -221,6 +221,40 @@ def test_scheduled_gates_are_a_padded_per_slice_permutation():
         sep = np.ascontiguousarray(ir.slice_edge_ptr, np.int32)
         _lib.check(_lib.lib().qp_schedule_gates(ir.T, _lib.ptr(sep), _lib.ptr(eu), _lib.ptr(ev), _lib.ptr(sptr.copy()),
                                                 _lib.ptr(sched), len(sched) - 1))
+
+
+@pytest.mark.parametrize("Q", [5, 40, 64, 100, 270, 512])
+def test_grouped_gates_are_a_padded_per_group_permutation(Q):
+    """Short rows: the gates of the G slices a wave takes per step, endpoints as byte offsets into those rows."""
+    from quantum_simulator_amd import layered_gate_arrays
+    T = 45
+    q0, q1, _ = layered_gate_arrays(Q, T, 0.5, seed=Q)
+    keep = np.random.default_rng(Q).random(len(q0)) > 0.3
+    ir = CircuitIR.from_gate_tables(Q, q0[keep], q1[keep])
+    ldq = (Q + 15) // 16 * 16
+    G = _lib.lib().qp_group_rows(ldq)
+    assert G == 64 // (ldq // 16)
+    gptr, sched = ir.grouped_edges(ldq)
+    ch, tail = _lib.QP_SCHED_CHUNK, _lib.QP_SCHED_TAIL
+    ng = (ir.T + G - 1) // G
+    assert len(gptr) == ng + 1 and gptr[0] == 0 and len(sched) == gptr[-1] + tail and not sched[gptr[-1]:].any()
+    for j in range(ng):
+        want = []
+        for t in range(j * G, min(ir.T, (j + 1) * G)):
+            off = (t - j * G) * ldq
+            for e in range(ir.slice_edge_ptr[t], ir.slice_edge_ptr[t + 1]):
+                want.append((off + int(ir.edge_u[e])) | ((off + int(ir.edge_v[e])) << 16))
+        s0, s1 = gptr[j], gptr[j + 1]
+        assert s1 - s0 == (len(want) + ch - 1) // ch * ch
+        assert sorted(want) == sorted(sched[s0:s0 + len(want)].tolist())
+        assert not sched[s0 + len(want):s1].any()  # padding: byte 0 with itself
+    assert _lib.lib().qp_group_rows(528) == 0 and _lib.lib().qp_group_rows(24) == 0
+    assert ir.grouped_edges(1024) is None
+    with pytest.raises(_lib.QplaceError):  # too little room
+        eu, ev = ir.edge_u.astype(np.uint16), ir.edge_v.astype(np.uint16)
+        sep = np.ascontiguousarray(ir.slice_edge_ptr, np.int32)
+        _lib.check(_lib.lib().qp_schedule_gate_groups(ir.T, _lib.ptr(sep), _lib.ptr(eu), _lib.ptr(ev), ldq,
+                                                      _lib.ptr(gptr.copy()), _lib.ptr(sched), len(sched) - 1))
 
 
 def _grid_metric(D):

@@ -17,13 +17,13 @@ from quantum_simulator_amd.timeslices import CircuitIR  # noqa: E402
 def main():
     dev = torch.device("cuda", 0)
     eng = Engine(dev)
-    print(f"{'Q':>5} {'mesh':>7} {'weights':>8} {'table':>22} {'ms':>8} {'G evals/s':>10} {'GB/s':>7}")
-    for Q in (64, 256, 512, 1024, 2048, 4096):
-        T = 500
-        B = max(64, (1 << 31) // (Q * T) // 2)  # about 1 GB of partitions
+    print(f"{'Q':>5} {'T':>5} {'mesh':>7} {'weights':>8} {'table':>22} {'ms':>8} {'G evals/s':>10} {'GB/s':>7}")
+    # (qubits, slices): the first two have the shapes of the shipped qft_n18 and qft_n63 circuits
+    for Q, T in ((18, 138), (63, 498), (64, 500), (256, 500), (256, 2046), (512, 500), (1024, 500), (2048, 500), (4096, 500)):
         q0, q1, _ = layered_gate_arrays(Q, T, 0.5, seed=Q)
         ir = CircuitIR.from_gate_tables(Q, q0, q1)
         dc = DeviceCircuit(ir, dev)
+        B = max(64, (1 << 31) // (dc.ldq * T) // 2)  # about 1 GB of partitions
         for nx in (4, 8, 16):
             C = nx * nx
             g = torch.Generator(device=dev)
@@ -52,7 +52,7 @@ def main():
                     how = ("closed form" if table == "packed" and dt.kind == 1 and dt.grid.valid else
                            "u16 look-up" if dt.kind == 1 else "f64 pair counts" if C * C * 8 > 140 * 1024 and 512 < dc.ldq <= 1024 and dt.symmetric
                            else "f64 look-up (L2)" if C * C * 8 > 140 * 1024 else "f64 look-up")
-                    print(f"{Q:5d} {nx:3d}x{nx:<3d} {wname:>8} {how:>22} {ms:8.3f} {B * T / ms / 1e6:10.2f} {B * T * dc.ldq / ms / 1e6:7.0f}", flush=True)
+                    print(f"{Q:5d} {T:5d} {nx:3d}x{nx:<3d} {wname:>8} {how:>22} {ms:8.3f} {B * T / ms / 1e6:10.2f} {B * T * dc.ldq / ms / 1e6:7.0f}", flush=True)
             del A
             torch.cuda.empty_cache()
 
