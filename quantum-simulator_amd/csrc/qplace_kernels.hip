@@ -104,6 +104,8 @@ constexpr int kTabLdsBand = 3; // LDS holds rows [band_lo, band_lo + band_rows) 
                                // pairs whose source core is outside the band read the zero entry, and the
                                // launcher runs one pass per band (for fp64 tables too big for LDS)
 constexpr int kTabGrid = 4;    // no table: the distance is a grid metric computed from the two core ids
+constexpr int kTabPairs = 5;   // no look-ups: unordered core pairs are counted in LDS and multiplied by the symmetrised
+                               // table once per item (fp64 tables too large for LDS; k_cost_v3_pairs, k_cost_v3_wide)
 
 // ------------------------------------------------------------------------------------------------
 // Cost V3: dense partitions, HQA-family definition.
@@ -958,6 +960,42 @@ __device__ inline void count_keys(uint32_t x, uint32_t base) {
     __hip_atomic_fetch_add((lds_u32*)(uintptr_t)a1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// the four (previous, current) pairs of a dword; a qubit that stayed counts into a diagonal slot
+__device__ inline void count_moves4(uint32_t pf, uint32_t cf, uint32_t base) {
+    count_keys(fold_keys(__builtin_amdgcn_perm(pf, cf, 0x05010400u), __builtin_amdgcn_perm(cf, pf, 0x05010400u)), base);
+    count_keys(fold_keys(__builtin_amdgcn_perm(pf, cf, 0x07030602u), __builtin_amdgcn_perm(cf, pf, 0x07030602u)), base);
+}
+// two gates: the cores of their first qubits in the 16-bit halves of u2, of their second qubits in v2
+__device__ inline void count_gate_pair2(uint32_t u2, uint32_t v2, uint32_t base) {
+    if (u2 != v2) count_keys(fold_keys(u2 << 8 | v2, v2 << 8 | u2), base);
+}
+// sum over all slots of count * symmetrised entry, in a fixed order, zeroing the counters on the way; table
+// entries are loaded whether or not the pair occurred (coalesced, cache-resident), sixteen at a time, so the loop
+// is not a chain of load latencies; an unused entry may be infinite: select, not multiply
+template <int THREADS>
+__device__ inline double apply_pair_counts(uint32_t* cnt, const double* fold) {
+    double acc = 0.0;
+    constexpr int kBatch = 16;  // slots per thread whose table entries are in flight together
+    static_assert(kPairSlots % (kBatch * THREADS) == 0, "whole batches of slots per thread");
+    for (int k0 = threadIdx.x; k0 < kPairSlots; k0 += kBatch * THREADS) {
+        double d[kBatch];
+        uint32_t n[kBatch];
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            d[j] = fold[k0 + j * THREADS];
+            n[j] = cnt[k0 + j * THREADS];
+        }
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            if (n[j]) {
+                cnt[k0 + j * THREADS] = 0;
+                acc += (double)n[j] * d[j];
+            }
+        }
+    }
+    return acc;
+}
+
 template <int AHEAD = kV3Ahead>
 __global__ __launch_bounds__(kV3Threads) void k_cost_v3_pairs(V3Args p) {
     extern __shared__ __align__(16) uint8_t smem[];
@@ -982,15 +1020,8 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_pairs(V3Args p) {
         const int nb = min(4, max(0, nvalid_row - 4 * w));
         keep[w] = nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u);
     }
-    // the four (previous, current) pairs of a dword; a qubit that stayed counts into a diagonal slot
-    auto count4 = [&](uint32_t pf, uint32_t cf) {
-        count_keys(fold_keys(__builtin_amdgcn_perm(pf, cf, 0x05010400u), __builtin_amdgcn_perm(cf, pf, 0x05010400u)), cbase);
-        count_keys(fold_keys(__builtin_amdgcn_perm(pf, cf, 0x07030602u), __builtin_amdgcn_perm(cf, pf, 0x07030602u)), cbase);
-    };
-    // two gates: the cores of their first qubits in the halves of u2, of their second qubits in v2
-    auto count_gates2 = [&](uint32_t u2, uint32_t v2) {
-        if (u2 != v2) count_keys(fold_keys(u2 << 8 | v2, v2 << 8 | u2), cbase);
-    };
+    auto count4 = [&](uint32_t pf, uint32_t cf) { count_moves4(pf, cf, cbase); };
+    auto count_gates2 = [&](uint32_t u2, uint32_t v2) { count_gate_pair2(u2, v2, cbase); };
 
     for (int64_t it = blockIdx.x; it < p.nitems; it += gridDim.x) {
         const int chunk = (int)(it / p.B);
@@ -1106,27 +1137,7 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_pairs(V3Args p) {
                 if (g0 + k < w1) do_row(g0 + k, ring[k], gring[k], sring[k], ering[k], false);
         }
         __syncthreads();
-        // table entries are loaded whether or not the pair occurred (coalesced, cache-resident), sixteen at a
-        // time, so the loop is not a chain of load latencies; an unused entry may be infinite: select, not multiply
-        double acc = 0.0;
-        constexpr int kBatch = 16;  // slots per thread whose table entries are in flight together
-        static_assert(kPairSlots % (kBatch * kV3Threads) == 0, "whole batches of slots per thread");
-        for (int k0 = threadIdx.x; k0 < kPairSlots; k0 += kBatch * kV3Threads) {
-            double d[kBatch];
-            uint32_t n[kBatch];
-#pragma unroll
-            for (int j = 0; j < kBatch; ++j) {
-                d[j] = fold[k0 + j * kV3Threads];
-                n[j] = cnt[k0 + j * kV3Threads];
-            }
-#pragma unroll
-            for (int j = 0; j < kBatch; ++j) {
-                if (n[j]) {
-                    cnt[k0 + j * kV3Threads] = 0;
-                    acc += (double)n[j] * d[j];
-                }
-            }
-        }
+        double acc = apply_pair_counts<kV3Threads>(cnt, fold);
         acc = wave_sum(acc);
         if (lane == 0) red[wave] = acc;
         __syncthreads();
@@ -1329,6 +1340,14 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void k_cost_v3_wid
         tab_off = stage_table(smem, p.table, p.table_bytes);
         tab = reinterpret_cast<const E*>(smem);
     }
+    // kTabPairs: the counters of the unordered core pairs come first (p.table is the symmetrised, folded table)
+    const uint32_t cbase = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_u8*)smem - 0x20000u);
+    if constexpr (TABMODE == kTabPairs) {
+        static_assert(KIND == QP_DT_F64 && NP == 1, "pair counts stand in for an fp64 table, rows of up to 16 KB");
+        tab_off = (uint32_t)(kPairSlots * sizeof(uint32_t));
+        for (int k = threadIdx.x; k < kPairSlots; k += THREADS) reinterpret_cast<uint32_t*>(smem)[k] = 0;
+        __syncthreads();
+    }
     uint8_t* strips = smem + tab_off;
     double* red = reinterpret_cast<double*>(strips);  // the per-wave sums of an item reuse the strips' first bytes
     const uint32_t C = (uint32_t)p.C, last = C * C - 1u;  // a core id >= C (caller's error) never reads past a table
@@ -1382,6 +1401,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void k_cost_v3_wid
         };
         auto gate_cost = [&](uint32_t u, uint32_t v) {
             if constexpr (TABMODE == kTabGrid) gacc.add4(p, u, v);
+            else if constexpr (TABMODE == kTabPairs) count_gate_pair2(u, v, cbase);  // upper halves: (0, 0), a diagonal slot
             else if (u != v) acc += pair_at(u, v);
         };
         uint32_t prev[NP][4];
@@ -1445,6 +1465,8 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void k_cost_v3_wid
                             const uint32_t pf = prev[k][w], cf = cur[k][w];
                             if constexpr (TABMODE == kTabGrid) {
                                 gacc.add4(p, pf, cf);
+                            } else if constexpr (TABMODE == kTabPairs) {
+                                if (pf != cf) count_moves4(pf, cf, cbase);
                             } else if (pf != cf) {
                                 if constexpr (TABMODE == kTabGlobal) {  // a look-up is an L2 gather: only for qubits that moved
 #pragma unroll
@@ -1483,6 +1505,9 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void k_cost_v3_wid
                         }
                         if constexpr (TABMODE == kTabGrid) {
                             gacc.add4(p, au[0] | au[1] << 8 | au[2] << 16 | au[3] << 24, av[0] | av[1] << 8 | av[2] << 16 | av[3] << 24);
+                        } else if constexpr (TABMODE == kTabPairs) {
+                            count_gate_pair2(au[0] | au[1] << 16, av[0] | av[1] << 16, cbase);
+                            count_gate_pair2(au[2] | au[3] << 16, av[2] | av[3] << 16, cbase);
                         } else {
                             Acc d4[4];
 #pragma unroll
@@ -1506,8 +1531,14 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void k_cost_v3_wid
             }
         }
         double s;
-        if constexpr (TABMODE == kTabGrid) s = gacc.total(p);
-        else s = wave_sum(acc);
+        if constexpr (TABMODE == kTabGrid) {
+            s = gacc.total(p);
+        } else if constexpr (TABMODE == kTabPairs) {
+            __syncthreads();  // every count of the item is in
+            s = wave_sum(apply_pair_counts<THREADS>(reinterpret_cast<uint32_t*>(smem), static_cast<const double*>(p.table)));
+        } else {
+            s = wave_sum(acc);
+        }
         __syncthreads();  // nobody reads a strip any more
         if (lane == 0) red[wave] = s;
         __syncthreads();
@@ -1920,7 +1951,8 @@ int slice_cost_v3_impl(const QpCircuit* circ, const QpDTable* dt, const uint8_t*
     // rows longer than 1 KB: workgroup size, LDS contents and rows per item of k_cost_v3_wide
     int wide_threads = kV3Threads;
     size_t wide_tab = 0, wide_strips = 0;
-    bool wide_two = false;
+    bool wide_two = false, wide_pairs = false;
+    double* wide_fold = nullptr;
     if (!narrow) {
         if (ldq / 16 > kWidePieces * kV3Threads) return qp::fail(QP_EINVAL, "qp_slice_cost_v3: rows longer than 65536 bytes");
         const bool gridpath = dt->kind == QP_DT_U16 && dt->grid.valid;
@@ -1938,6 +1970,25 @@ int slice_cost_v3_impl(const QpCircuit* circ, const QpDTable* dt, const uint8_t*
         int P = 128;
         while (P < ldq / 16 && P < wide_threads) P *= 2;
         p.rows_per_item = std::min<int>(T, std::max(p.rows_per_item, 32 * (wide_threads / P)));
+        // fp64 table that does not fit beside the strips but is symmetric to rounding, rows of up to 16 KB: pair
+        // counts instead of gathers from device memory.  One 1024-thread workgroup per CU (the counters take
+        // 128 KB); long items, about 8 per workgroup, since every item ends with a pass over all counters
+        if (dt->kind == QP_DT_F64 && dt->symmetric && dt->C >= 2 && wide_tab == 0 && ldq / 16 <= kV3Threads) {
+            int P1 = 128;
+            while (P1 < ldq / 16) P1 *= 2;
+            const int64_t want = ((int64_t)T * B + (int64_t)cus * 8 - 1) / ((int64_t)cus * 8);
+            const int rows = (int)std::min<int64_t>(T, std::max<int64_t>(32 * (kV3Threads / P1), want));
+            const int64_t items = (int64_t)((T + rows - 1) / rows) * B;
+            const size_t part_bytes = ((size_t)items * sizeof(double) + 255) & ~(size_t)255;
+            if (workspace && workspace_bytes >= part_bytes + (size_t)kPairSlots * sizeof(double)) {
+                wide_pairs = true;
+                wide_fold = reinterpret_cast<double*>(static_cast<uint8_t*>(workspace) + part_bytes);
+                wide_threads = kV3Threads;
+                wide_strips = (size_t)kV3Threads * 16;
+                wide_two = (size_t)kPairSlots * sizeof(uint32_t) + 2 * wide_strips <= (size_t)kLdsBytes;
+                p.rows_per_item = rows;
+            }
+        }
     }
     const int32_t nchunks = (T + p.rows_per_item - 1) / p.rows_per_item;
     p.nitems = (int64_t)nchunks * B;
@@ -2116,7 +2167,12 @@ int slice_cost_v3_impl(const QpCircuit* circ, const QpDTable* dt, const uint8_t*
     (half ? k_cost_v3_wide<KIND, MODE, 1, 2, kV3Threads / 2> \
      : one ? (two ? k_cost_v3_wide<KIND, MODE, 1, 2, kV3Threads> : k_cost_v3_wide<KIND, MODE, 1, 1, kV3Threads>) \
            : (two ? k_cost_v3_wide<KIND, MODE, kWidePieces, 2, kV3Threads> : k_cost_v3_wide<KIND, MODE, kWidePieces, 1, kV3Threads>))
-        if (gridpath) {
+        if (wide_pairs) {
+            k_sym_fold<<<kPairSlots / 256, 256, 0, stream>>>(static_cast<const double*>(dt->table), dt->C, wide_fold);
+            HIP_TRY(hipGetLastError());
+            p.table = wide_fold;
+            kern = two ? k_cost_v3_wide<QP_DT_F64, kTabPairs, 1, 2, kV3Threads> : k_cost_v3_wide<QP_DT_F64, kTabPairs, 1, 1, kV3Threads>;
+        } else if (gridpath) {
             if (int rc = fill_grid_args(p, dt)) return rc;
             kern = QP_WIDE(QP_DT_U16, kTabGrid);
         } else if (dt->kind == QP_DT_F64) {
@@ -2125,7 +2181,7 @@ int slice_cost_v3_impl(const QpCircuit* circ, const QpDTable* dt, const uint8_t*
             kern = tab_lds ? QP_WIDE(QP_DT_U16, kTabLdsC) : QP_WIDE(QP_DT_U16, kTabGlobal);
         }
 #undef QP_WIDE
-        const size_t lds = wide_tab + (two ? 2 : 1) * wide_strips;
+        const size_t lds = (wide_pairs ? (size_t)kPairSlots * sizeof(uint32_t) : wide_tab) + (two ? 2 : 1) * wide_strips;
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int per_cu = 1;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), threads, lds));

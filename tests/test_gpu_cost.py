@@ -526,7 +526,10 @@ def test_cost_v3_full_size_against_c_oracle(gpu, integer):
 
 WIDE = [  # Q, T, topology, nx, ny, integer weight (0 = uniform(1,3)), B, share of qubits that move per row
     (2048, 70, "mesh", 4, 4, 2.0, 3, 0.1),       # closed form and uint16 table in LDS
-    (1100, 300, "mesh", 16, 16, 0, 2, 0.05),     # fp64 table of 256 cores stays in device memory; two chunks
+    (1100, 300, "mesh", 16, 16, 0, 2, 0.05),     # fp64 table of 256 cores: core pairs are counted in LDS
+    (2048, 260, "mesh", 16, 16, 0, 5, 1.0),      # the same with every qubit moving, eight rows per workgroup step
+    (5000, 40, "mesh", 14, 14, 0, 3, 0.5),       # 196 cores, 313 pieces per row
+    (16384, 6, "torus", 16, 16, 0, 2, 0.3),      # the longest rows that are counted: one row per workgroup step
     (3000, 20, "torus", 8, 8, 1.0, 2, 1.0),      # rings; every qubit moves
     (1500, 33, "star", 9, 1, 0, 2, 0.3),         # fp64 table in LDS, pieces not a power of two
     (4099, 9, "mesh", 4, 3, 3.0, 2, 0.5),        # integer table without a closed form
@@ -567,6 +570,10 @@ def test_cost_v3_wide_rows(gpu, Q, T, topo, nx, ny, wt, B, pmove):
     got = eng.cost_v3(dc, dt, Ad).cpu().numpy()
     if wt:
         assert got.tobytes() == eng.cost_v3(dc, dt, Ad, table="table").cpu().numpy().tobytes()
+    elif C * C * 8 > 150 * 1024 and dc.ldq <= 16384:
+        # counted pairs times the symmetrised table against look-ups of the directed entries
+        looked_up = eng.cost_v3(dc, dt, Ad, table="table").cpu().numpy()
+        assert all(_close(looked_up[b], got[b], False) for b in range(B)), (looked_up, got)
     assert got.tobytes() == eng.cost_v3(dc, dt, Ad).cpu().numpy().tobytes()
     # a caller that passes no padded gate list: the gates come from the edge records (another order of terms)
     saved = dc.c.edges_sched, dc.c.sched_ptr

@@ -50,7 +50,7 @@ def main():
                     torch.cuda.synchronize()
                     ms = e0.elapsed_time(e1) / 5
                     how = ("closed form" if table == "packed" and dt.kind == 1 and dt.grid.valid else
-                           "u16 look-up" if dt.kind == 1 else "f64 pair counts" if C * C * 8 > 140 * 1024 and 512 < dc.ldq <= 1024 and dt.symmetric
+                           "u16 look-up" if dt.kind == 1 else "f64 pair counts" if C * C * 8 > 140 * 1024 and 512 < dc.ldq <= 16384 and dt.symmetric
                            else "f64 look-up (L2)" if C * C * 8 > 140 * 1024 else "f64 look-up")
                     print(f"{Q:5d} {T:5d} {nx:3d}x{nx:<3d} {wname:>8} {how:>22} {ms:8.3f} {B * T / ms / 1e6:10.2f} {B * T * dc.ldq / ms / 1e6:7.0f}", flush=True)
             del A
