@@ -1151,6 +1151,133 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_pairs(V3Args p) {
     }
 }
 
+// The same for rows of at most 512 bytes (grouped gate list, G rows per wave step as in k_cost_v3_groups): the
+// item's steps are dealt to the workgroup's waves in runs, every wave parks its steps in its own strip
+// [row before][G rows] and counts into the shared counters.
+template <int AHEAD = kV3Ahead>
+__global__ __launch_bounds__(kV3Threads) void k_cost_v3_pairs_groups(V3Args p) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int ldq = p.ldq, G = p.G, lpr = p.lpr;
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(smem);
+    uint8_t* strip = smem + (size_t)kPairSlots * 4 + (size_t)wave * (G + 1) * ldq;  // [row before][G rows]
+    uint8_t* rows = strip + ldq;
+    double* red = reinterpret_cast<double*>(smem + (size_t)kPairSlots * 4 + (size_t)kV3Waves * (G + 1) * ldq);
+    const uint32_t cbase = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_u8*)smem - 0x20000u);
+    const double* fold = static_cast<const double*>(p.table);
+    for (int k = threadIdx.x; k < kPairSlots; k += kV3Threads) cnt[k] = 0;
+    __syncthreads();
+
+    const bool lane_on = lane < G * lpr;
+    const int lrow = lane_on ? lane / lpr : 0;
+    const int lq0 = lane_on ? (lane - lrow * lpr) * 16 : 0;
+    const int lane_off = lane_on ? lane * 16 : 0;
+    const bool last_row = lane_on && lrow == G - 1;
+    const int nvalid_row = lane_on ? min(16, max(0, p.Q - lq0)) : 0;
+    uint32_t keep[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const int nb = min(4, max(0, nvalid_row - 4 * w));
+        keep[w] = nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u);
+    }
+    const uint32_t* gsched_lane = p.gsched + lane;
+    // byte 0 of two gathered values into the 16-bit halves of one register
+    auto halves = [](uint32_t x0, uint32_t x1) { return __builtin_amdgcn_perm(x1, x0, 0x0c040c00u); };
+
+    for (int64_t it = blockIdx.x; it < p.nitems; it += gridDim.x) {
+        const int chunk = (int)(it / p.B);
+        const int64_t b = it - (int64_t)chunk * p.B;
+        const int r0 = chunk * p.rows_per_item;  // a multiple of G
+        const int r1 = min(p.T, r0 + p.rows_per_item);
+        const int isteps = (r1 - r0 + G - 1) / G;
+        // this wave's run of the item's steps (runs differ by at most one step)
+        const int sb = isteps * wave / kV3Waves, se = isteps * (wave + 1) / kV3Waves;
+        const uint8_t* base = p.A + (size_t)b * p.Tp * ldq;
+        if (sb < se) {
+            const int rw = r0 + sb * G;        // first row of the run
+            const int nsteps = se - sb;
+            const int j0 = rw / G, jlast = j0 + nsteps - 1;
+            auto fetch_rows = [&](int s) -> uint4 {
+                const int rowl = min(rw + s * G + lrow, r1 - 1);
+                return load_row16(base + ((uint32_t)rowl * (uint32_t)ldq + (uint32_t)lq0));
+            };
+            auto fetch_gate = [&](int s, int c) -> uint32_t {
+                const uint32_t* gp = gsched_lane + p.gptr[min(j0 + s, jlast)];
+                return gp[c * kWave];
+            };
+            if (rw >= 1 && lane < lpr)
+                *reinterpret_cast<uint4*>(strip + lane * 16) =
+                    *reinterpret_cast<const uint4*>(base + (size_t)(rw - 1) * ldq + lane * 16);
+            uint4 ring[AHEAD];
+            uint32_t gring[AHEAD][kRowEdgeChunks];
+#pragma unroll
+            for (int k = 0; k < AHEAD; ++k) {
+                ring[k] = fetch_rows(k);
+#pragma unroll
+                for (int c = 0; c < kRowEdgeChunks; ++c) gring[k][c] = fetch_gate(k, c);
+            }
+            for (int s0 = 0; s0 < nsteps; s0 += AHEAD) {
+#pragma unroll
+                for (int k = 0; k < AHEAD; ++k) {
+                    const int s = s0 + k;
+                    if (s >= nsteps) break;
+                    const uint4 cur = ring[k];
+                    uint32_t gates[kRowEdgeChunks];
+#pragma unroll
+                    for (int c = 0; c < kRowEdgeChunks; ++c) gates[c] = gring[k][c];
+                    ring[k] = fetch_rows(s + AHEAD);
+#pragma unroll
+                    for (int c = 0; c < kRowEdgeChunks; ++c) gring[k][c] = fetch_gate(s + AHEAD, c);
+                    uint4 prv = make_uint4(0, 0, 0, 0);
+                    if (lane_on) {
+                        *reinterpret_cast<uint4*>(rows + lane_off) = cur;
+                        prv = *reinterpret_cast<const uint4*>(strip + lane_off);
+                    }
+                    const int w0 = p.gptr[j0 + s];
+                    const int nch = (p.gptr[j0 + s + 1] - w0) / kWave;
+                    uint32_t au[kRowEdgeChunks], av[kRowEdgeChunks];
+#pragma unroll
+                    for (int c = 0; c < kRowEdgeChunks; ++c) {  // a chunk the group lacks: one byte twice
+                        const uint32_t g = c < nch ? gates[c] : 0u;
+                        au[c] = rows[g & 0xFFFFu];
+                        av[c] = rows[g >> 16];
+                    }
+                    count_gate_pair2(halves(au[0], au[1]), halves(av[0], av[1]), cbase);
+                    count_gate_pair2(halves(au[2], au[3]), halves(av[2], av[3]), cbase);
+                    for (int c = kRowEdgeChunks; c < nch; ++c) {
+                        const uint32_t g = gsched_lane[w0 + c * kWave];
+                        const uint32_t u = rows[g & 0xFFFFu], v = rows[g >> 16];
+                        count_gate_pair2(u, v, cbase);  // the upper halves are the pair (0, 0): a diagonal slot
+                    }
+                    // movement: rows 2 .. r1 - 1; everything else compares a piece with itself and is skipped
+                    const int row = rw + s * G + lrow;
+                    const bool mv = row >= 2 && row < r1;
+                    const uint32_t cw[4] = {cur.x, cur.y, cur.z, cur.w};
+                    const uint32_t pw[4] = {mv ? prv.x : cur.x, mv ? prv.y : cur.y, mv ? prv.z : cur.z, mv ? prv.w : cur.w};
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const uint32_t pm = pw[w] & keep[w], cm = cw[w] & keep[w];
+                        if (pm != cm) count_moves4(pm, cm, cbase);
+                    }
+                    if (last_row) *reinterpret_cast<uint4*>(strip + lq0) = cur;
+                }
+            }
+        }
+        __syncthreads();
+        double acc = wave_sum(apply_pair_counts<kV3Threads>(cnt, fold));
+        if (lane == 0) red[wave] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double s = 0.0;
+            for (int w = 0; w < kV3Waves; ++w) s += red[w];
+            p.partial[it] = s;
+        }
+        // the next item's counting cannot pass the barrier after it before thread 0 has read red[]; its
+        // counter updates touch entries this pass has already zeroed or left at zero
+    }
+}
+
 // Rows longer than 512 bytes under a grid metric (no table).  Written for a low vector-instruction
 // count, which is what bounds it once nothing is looked up: row and gate loads use wave-uniform base
 // pointers plus a fixed per-lane offset; strips sit at a pitch of 1024 bytes; the previous row is
@@ -2006,9 +2133,37 @@ int slice_cost_v3_impl(const QpCircuit* circ, const QpDTable* dt, const uint8_t*
         q.rows_per_item = (int)(spi * G);
         const int32_t gchunks = (T + q.rows_per_item - 1) / q.rows_per_item;
         q.nitems = (int64_t)gchunks * B;
+        const size_t gstrips = (size_t)kV3Waves * (G + 1) * ldq;
+        if (dt->kind == QP_DT_F64 && dt->symmetric && dt->C >= 2 && tab_padded + gstrips > (size_t)kLdsBytes &&
+            (int64_t)T * ldq >= 32768) {
+            // fp64 table too large for LDS, symmetric to rounding, partitions of 32 KB or more: pair counts, a
+            // workgroup per item (about 8 items per workgroup: every item ends with a pass over all counters, which
+            // costs as much as counting 30 KB of rows; below that size the gathers from device memory are no slower)
+            V3Args c = p;
+            const int64_t want = (steps_total * B + (int64_t)cus * 8 - 1) / ((int64_t)cus * 8);
+            const int64_t cspi = std::min<int64_t>(steps_total, std::max<int64_t>(2 * kV3Waves, want));
+            c.rows_per_item = (int)(cspi * G);
+            const int32_t cchunks = (T + c.rows_per_item - 1) / c.rows_per_item;
+            c.nitems = (int64_t)cchunks * B;
+            const size_t part_bytes = ((size_t)c.nitems * sizeof(double) + 255) & ~(size_t)255;
+            const size_t clds = (size_t)kPairSlots * sizeof(uint32_t) + gstrips + kV3Waves * sizeof(double);
+            if (clds <= (size_t)kLdsBytes && workspace_bytes >= part_bytes + (size_t)kPairSlots * sizeof(double)) {
+                double* fold = reinterpret_cast<double*>(static_cast<uint8_t*>(workspace) + part_bytes);
+                k_sym_fold<<<kPairSlots / 256, 256, 0, stream>>>(static_cast<const double*>(dt->table), dt->C, fold);
+                HIP_TRY(hipGetLastError());
+                c.table = fold;
+                void (*kern)(V3Args) = k_cost_v3_pairs_groups<kV3Ahead>;
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)clds));
+                kern<<<(unsigned)std::min<int64_t>(cus, c.nitems), kV3Threads, clds, stream>>>(c);
+                HIP_TRY(hipGetLastError());
+                k_sum_chunks<<<(unsigned)((B + 255) / 256), 256, 0, stream>>>(c.partial, B, cchunks, out);
+                HIP_TRY(hipGetLastError());
+                return QP_OK;
+            }
+        }
         if (workspace_bytes >= (size_t)q.nitems * sizeof(double)) {
             const bool gridpath = dt->kind == QP_DT_U16 && dt->grid.valid;
-            const size_t strips = (size_t)kV3Waves * (G + 1) * ldq;
+            const size_t strips = gstrips;
             const size_t tab256 = (size_t)dt->C * 256 * esz;
             void (*kern)(V3Args) = nullptr;
             size_t lds = strips;

@@ -124,7 +124,14 @@ def main():
         return [pick(2, 80), pick(81, 512), pick(513, 1024), pick(1025, 1600)][pick(0, 3)]
 
     def draw():
-        kind = pick(0, 10)
+        kind = pick(0, 11)
+        if kind == 11:  # rows of at most 512 bytes through the grouped gate list: every table form, one or several items
+            Q = pick(2, 512)
+            ldq = (Q + 15) // 16 * 16
+            T = pick(1, max(1, min(9000, 400000 // ldq)))
+            integer = bool(pick(0, 1))
+            return "cost_v3_short_rows", TC.test_cost_v3_short_rows_in_groups, (gpu, Q, T, pick(2, 256), pick(1, 40), integer,
+                                                                                float(rng.choice([0.02, 0.3, 1.0])))
         if kind == 10:  # long rows, table in LDS, 64 partitions or more: four partitions per wave step
             integer = bool(pick(0, 1))
             return "cost_v3_four_partitions", TC.test_cost_v3_four_partitions_per_wave, (gpu, pick(513, 1024), pick(1, 80), pick(2, 256) if integer else pick(2, 64),
