@@ -20,7 +20,8 @@ HBM: algorithmic bytes per launch / mean launch time from HIP events on the laun
 The headline variant is the reference's default arithmetic (uniform random edge weights, fp64 distance
 table); ``other_variants`` repeats the measurement with integer weights (closed-form grid metric) and with
 the same integer table looked up in LDS, ``roofline_by_weights`` lists the three side by side; ``gtrhqa_place``, ``cost_matrix`` and ``qubo`` time the other device paths, ``shipped_circuits``
-whole placement + cost batches of every placer on two of the reference's own circuits.
+whole placement + cost batches of every placer on two of the reference's own circuits, ``shipped_circuits_cost_at_scale``
+the cost launch alone on half a GB of partitions of three of them (rows of 32 to 256 bytes).
 ``cpu_baseline`` times the CPU oracle (a C port of the reference's per_timeslice_cost loop) on a bounded
 sample of the same partitions on every host core, each result checked against the GPU's.
 """
@@ -193,6 +194,53 @@ def bench_shipped(dev, rank=0, world=1):
                          "mean_cost": float(sums[0, pi, 0] / sums[0, pi, 1]) if sums[0, pi, 1] else math.inf,
                          "min_cost": float(mins[0, pi]), "finite_repeats": int(sums[0, pi, 1]),
                          "reduce_ms": reduce_ms if world > 1 else None})
+    return rows
+
+
+def bench_shipped_cost(torch, dev, steps=20):
+    """Cost evaluation at scale on the reference's shipped circuits (gate tables and networks from tests/golden):
+    for the circuit and network of cfg1 (256-qubit QFT, mesh 2x1, capacity 130), cfg2 (qft_n18, mesh 4x4) and cfg3
+    (qft_n63, torus 8x8), about half a GB of partitions -- GTRHQA's own placements from seeded shuffles of the block
+    assignment, computed on the device -- costed in one launch with the network's fp64 distance table.  Rows are
+    16 to 256 bytes here: a wave takes 4 to 32 slices per step (k_cost_v3_groups)."""
+    import numpy as np
+    from quantum_simulator_amd.golden import case_arch, case_circuit, load_case
+    from quantum_simulator_amd.placers import PLACERS
+    rows = []
+    for cfg, name in (("cfg1", "gen256_mesh2x1_u"), ("cfg2", "qft18_mesh4x4_u"), ("cfg3", "qft63_torus8x8_u")):
+        gc = load_case(name)
+        circ, arch = case_circuit(gc), case_arch(gc)
+        ctx = PLACERS["GTRHQA"](dev)._context(circ, arch)
+        ir, dc, dt, eng = ctx.ir, ctx.dc, ctx.arch.table, ctx.eng
+        C, cap, Q = ctx.arch.C, int(gc.meta["cap"]), ir.Q
+        B = max(64, (1 << 29) // ((ir.T + 1) * dc.ldq))
+        rng = np.random.default_rng(4242)
+        slots = np.repeat(np.arange(C), cap)
+        init = np.zeros((B, dc.ldq), np.uint8)
+        for b in range(B):
+            init[b, :Q] = rng.permutation(slots)[:Q] if b else np.arange(Q) // cap
+        A = eng.gtrhqa_place(dc, dt, torch.from_numpy(init).to(dev), cap)
+        out = torch.empty(B, dtype=torch.float64, device=dev)
+        for _ in range(3):
+            eng.cost_v3(dc, dt, A, out=out)
+        torch.cuda.synchronize(dev)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(torch.cuda.current_stream(dev))
+        for _ in range(steps):
+            eng.cost_v3(dc, dt, A, out=out)
+        ev1.record(torch.cuda.current_stream(dev))
+        torch.cuda.synchronize(dev)
+        ms = ev0.elapsed_time(ev1) / steps
+        alg = B * ir.T * dc.ldq + 4 * ir.nE + 4 * (ir.T + 1) + 8 * B + 8 * C * C
+        # the first partition is the block assignment: its cost is what the reference's GTRHQA run reports
+        rows.append({"config": cfg, "case": name, "qubits": Q, "slices": ir.T, "cores": C, "row_bytes": dc.ldq,
+                     "partitions": B, "kernel_ms": ms, "evals_per_s": B * ir.T / (ms * 1e-3),
+                     "roofline": {"bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "alg_bytes_per_launch": alg},
+                     "cost_of_the_block_assignment_run": float(out[0].item()),
+                     "reference_gtrhqa_cost": gc.cost("GTRHQA") if gc.has("GTRHQA") else None})
+        del A
+        torch.cuda.empty_cache()
     return rows
 
 
@@ -465,11 +513,16 @@ def main():
                 raise  # the other ranks are waiting in a collective
             shipped = {"error": f"{type(exc).__name__}: {exc}"}
     broken = None
+    shipped_cost = None
     if world == 1 and not args.no_qubo:
         try:
             broken = bench_broken_links(torch, dev)
         except Exception as exc:  # noqa: BLE001 - a side table must not cost the headline line
             broken = {"error": f"{type(exc).__name__}: {exc}"}
+        try:
+            shipped_cost = bench_shipped_cost(torch, dev)
+        except Exception as exc:  # noqa: BLE001
+            shipped_cost = {"error": f"{type(exc).__name__}: {exc}"}
     if rank == 0:
         D, kind, gpu_costs = primary.pop("_D"), primary.pop("_kind"), primary.pop("_costs")
         res = {
@@ -485,7 +538,7 @@ def main():
                        "table": primary["table"]},
             "roofline": primary["roofline"], "mean_cost": primary["mean_cost"], "min_cost": primary["min_cost"],
             "reduce_ms": primary["reduce_ms"], "gtrhqa_place": place, "cost_matrix": cm, "qubo": qubo,
-            "shipped_circuits": shipped, "broken_links": broken,
+            "shipped_circuits": shipped, "shipped_circuits_cost_at_scale": shipped_cost, "broken_links": broken,
         }
         # HBM bytes per launch as measured with rocprofv3 PMC counters in a separate run of this workload
         # (profiles/r02_traffic.json, one entry per kernel name; FETCH_SIZE doubled as gfx950 requires for
