@@ -7,6 +7,7 @@
 #include <atomic>
 #include <cmath>
 #include <limits>
+#include <type_traits>
 
 #include "qplace_internal.h"
 
@@ -75,6 +76,24 @@ __device__ inline uint32_t stage_table_pitch256(uint8_t* smem, const void* table
     return (uint32_t)(C * 256 * sizeof(E));
 }
 
+// Small tables, every entry stored 2^rep_shift times side by side (16-bit entries widened to 32 bits): a lane
+// reads copy (lane & (copies - 1)), so the lanes of an instruction that use different copies can never meet in a
+// bank, whatever entries they want.  With 32 copies (up to 16 cores) no look-up ever waits for another; with 8 or 4
+// copies (up to 64 cores) only the lanes that share a copy can collide.  Index = from << BITS | to.
+template <typename E, int BITS>
+__device__ inline uint32_t stage_table_replicated(uint8_t* smem, const void* table, int C, int rep_shift) {
+    using S = typename std::conditional<sizeof(E) == 2, uint32_t, E>::type;  // what a copy is stored as
+    const E* src = static_cast<const E*>(table);
+    S* dst = reinterpret_cast<S*>(smem);
+    const int n = (1 << (2 * BITS)) << rep_shift;
+    for (int k = threadIdx.x; k < n; k += blockDim.x) {
+        const int idx = k >> rep_shift, r = idx >> BITS, c = idx & ((1 << BITS) - 1);
+        dst[k] = (r < C && c < C) ? (S)src[r * C + c] : S(0);
+    }
+    __syncthreads();
+    return (uint32_t)((size_t)n * sizeof(S));
+}
+
 typedef __attribute__((address_space(3))) uint8_t lds_u8;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 
@@ -104,6 +123,8 @@ constexpr int kTabLdsBand = 3; // LDS holds rows [band_lo, band_lo + band_rows) 
                                // pairs whose source core is outside the band read the zero entry, and the
                                // launcher runs one pass per band (for fp64 tables too big for LDS)
 constexpr int kTabGrid = 4;    // no table: the distance is a grid metric computed from the two core ids
+constexpr int kTabLdsRep4 = 6;  // LDS, up to 16 cores: index = from << 4 | to, every entry stored R times side by side
+constexpr int kTabLdsRep6 = 7;  // LDS, up to 64 cores: index = from << 6 | to, likewise (k_cost_v3_groups)
 constexpr int kTabPairs = 5;   // no look-ups: unordered core pairs are counted in LDS and multiplied by the symmetrised
                                // table once per item (fp64 tables too large for LDS; k_cost_v3_pairs, k_cost_v3_wide)
 
@@ -139,6 +160,7 @@ struct V3Args {
     int32_t T, Tp, ldq, Q, C, rows_per_item, G, lpr;
     uint32_t table_bytes;
     int32_t band_lo, band_rows;
+    int32_t rep_shift;  // kTabLdsRep*: log2 of the copies of every table entry (copy = lane & (copies - 1))
     // grid metric (kTabGrid): byte-replicated masks of the x and y fields of a core id, the shift that
     // brings y down, half the ring length per byte for a dimension that wraps (0 = does not wrap), weights
     uint32_t gxm, gym, gxb, ghalfx, ghalfy, gwx, gwy;
@@ -322,8 +344,8 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3(V3Args p) {
 // steps; a whole partition when it is shorter) so that the start of an item, where the first rows are waited for
 // with nothing else to do, is a small part of it.  TABMODE: kTabLds256, kTabLdsC, kTabGlobal, or kTabGrid (no table;
 // WRAP = some dimension of the grid is a ring).
-template <int KIND, int TABMODE, bool WRAP, int AHEAD = kV3Ahead>
-__global__ __launch_bounds__(kV3Threads) void k_cost_v3_groups(V3Args p) {
+template <int KIND, int TABMODE, bool WRAP, int THREADS = kV3Threads, int AHEAD = kV3Ahead>
+__global__ __launch_bounds__(THREADS) void k_cost_v3_groups(V3Args p) {
     extern __shared__ __align__(16) uint8_t smem[];
     using E = typename Tab<KIND>::elem;
     using Acc = typename Tab<KIND>::acc;
@@ -338,12 +360,32 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_groups(V3Args p) {
     } else if constexpr (TABMODE == kTabLdsC) {
         tab_off = stage_table(smem, p.table, p.table_bytes);
         tab = reinterpret_cast<const E*>(smem);
+    } else if constexpr (TABMODE == kTabLdsRep4) {
+        tab_off = stage_table_replicated<E, 4>(smem, p.table, p.C, p.rep_shift);
+        tab = reinterpret_cast<const E*>(smem);
+    } else if constexpr (TABMODE == kTabLdsRep6) {
+        tab_off = stage_table_replicated<E, 6>(smem, p.table, p.C, p.rep_shift);
+        tab = reinterpret_cast<const E*>(smem);
     } else {
         tab = static_cast<const E*>(p.table);
     }
+    constexpr bool kRep = TABMODE == kTabLdsRep4 || TABMODE == kTabLdsRep6;
+    constexpr int kRepBits = TABMODE == kTabLdsRep4 ? 4 : 6;
+    using RepE = typename std::conditional<sizeof(E) == 2, uint32_t, E>::type;  // a stored copy of an entry
+    typedef __attribute__((address_space(3))) const RepE lds_rep;
     const int ldq = p.ldq, G = p.G, lpr = p.lpr;
     const uint32_t C = (uint32_t)p.C;
     const uint32_t tbase = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_u8*)smem);
+    // replicated table: bytes between consecutive entries, and this lane's copy
+    const uint32_t rep_pitch = (uint32_t)sizeof(RepE) << p.rep_shift;
+    const uint32_t rep_base = tbase + (uint32_t)(lane & ((1 << p.rep_shift) - 1)) * (uint32_t)sizeof(RepE);
+    auto rep_at_halves = [&](uint32_t x, RepE& e0, RepE& e1) {  // the entries whose indices are the halves of x
+        uint32_t a0, a1;
+        asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[0,0,0,0]" : "=v"(a0) : "v"(x), "s"(rep_pitch), "v"(rep_base));
+        asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(a1) : "v"(x), "s"(rep_pitch), "v"(rep_base));
+        e0 = *(lds_rep*)(uintptr_t)a0;
+        e1 = *(lds_rep*)(uintptr_t)a1;
+    };
     auto in_table = [&](uint32_t idx) -> uint32_t {
         if constexpr (TABMODE == kTabGlobal) return min(idx, C * C - 1u);
         else return idx;
@@ -365,14 +407,35 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_groups(V3Args p) {
         ky[w] = keep[w] & p.gyi;
     }
     auto pair_at = [&](uint32_t from, uint32_t to) -> Acc {
-        if constexpr (TABMODE == kTabLds256) return tab[(from << 8) | to];
-        else return tab[in_table(__umul24(from, C) + to)];
+        if constexpr (TABMODE == kTabLds256) {
+            return tab[(from << 8) | to];
+        } else if constexpr (kRep) {
+            constexpr uint32_t m = (1u << kRepBits) - 1u;
+            const uint32_t a = __umul24(((from & m) << kRepBits) | (to & m), rep_pitch) + rep_base;
+            return (Acc) * (lds_rep*)(uintptr_t)a;
+        } else {
+            return tab[in_table(__umul24(from, C) + to)];
+        }
     };
     auto four = [&](uint32_t pf, uint32_t cf) -> Acc {
         if constexpr (TABMODE == kTabLds256) {
             E e0, e1, e2, e3;
             entries_at_halves<E>(__builtin_amdgcn_perm(pf, cf, 0x05010400u), tbase, e0, e1);
             entries_at_halves<E>(__builtin_amdgcn_perm(pf, cf, 0x07030602u), tbase, e2, e3);
+            return ((Acc)e0 + (Acc)e1) + ((Acc)e2 + (Acc)e3);
+        } else if constexpr (TABMODE == kTabLdsRep4) {
+            // core ids below 16: from << 4 | to of the four pairs is one byte each
+            const uint32_t k = ((pf & 0x0F0F0F0Fu) << 4) | (cf & 0x0F0F0F0Fu);
+            RepE e0, e1, e2, e3;
+            rep_at_halves(__builtin_amdgcn_perm(0u, k, 0x0c010c00u), e0, e1);
+            rep_at_halves(__builtin_amdgcn_perm(0u, k, 0x0c030c02u), e2, e3);
+            return ((Acc)e0 + (Acc)e1) + ((Acc)e2 + (Acc)e3);
+        } else if constexpr (TABMODE == kTabLdsRep6) {
+            // halves from << 8 | to -> from << 6 | to (ids below 64)
+            auto squeeze = [](uint32_t y) { return ((y >> 2) & 0x0FC00FC0u) | (y & 0x003F003Fu); };
+            RepE e0, e1, e2, e3;
+            rep_at_halves(squeeze(__builtin_amdgcn_perm(pf, cf, 0x05010400u)), e0, e1);
+            rep_at_halves(squeeze(__builtin_amdgcn_perm(pf, cf, 0x07030602u)), e2, e3);
             return ((Acc)e0 + (Acc)e1) + ((Acc)e2 + (Acc)e3);
         } else {
             Acc s = 0;
@@ -383,7 +446,7 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_groups(V3Args p) {
     };
     const uint32_t* gsched_lane = p.gsched + lane;
 
-    for (int64_t it = (int64_t)blockIdx.x * kV3Waves + wave; it < p.nitems; it += (int64_t)gridDim.x * kV3Waves) {
+    for (int64_t it = (int64_t)blockIdx.x * (THREADS / kWave) + wave; it < p.nitems; it += (int64_t)gridDim.x * (THREADS / kWave)) {
         const int chunk = (int)(it / p.B);
         const int64_t b = it - (int64_t)chunk * p.B;
         const int r0 = chunk * p.rows_per_item;  // a multiple of G
@@ -477,10 +540,24 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_groups(V3Args p) {
                         ay = __builtin_amdgcn_sad_u8(U & p.gyi, V & p.gyi, ay);
                     }
                 } else {
+                    if constexpr (TABMODE == kTabLdsRep4) {
+                        // look-ups that never collide: all sixteen go out together (no wait per dword) unless
+                        // nothing moved in the whole step
+                        uint32_t pm[4], cm[4];
 #pragma unroll
-                    for (int w = 0; w < 4; ++w) {  // a lane skips four qubits that all stayed where they were
-                        const uint32_t pm = pw[w] & keep[w], cm = cw[w] & keep[w];
-                        if (pm != cm) acc += four(pm, cm);
+                        for (int w = 0; w < 4; ++w) {
+                            pm[w] = pw[w] & keep[w];
+                            cm[w] = cw[w] & keep[w];
+                        }
+                        const bool moved = ((pm[0] ^ cm[0]) | (pm[1] ^ cm[1]) | (pm[2] ^ cm[2]) | (pm[3] ^ cm[3])) != 0;
+                        if (__builtin_amdgcn_ballot_w64(moved) != 0)
+                            acc += (four(pm[0], cm[0]) + four(pm[1], cm[1])) + (four(pm[2], cm[2]) + four(pm[3], cm[3]));
+                    } else {
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) {  // a lane skips four qubits that all stayed where they were
+                            const uint32_t pm = pw[w] & keep[w], cm = cw[w] & keep[w];
+                            if (pm != cm) acc += four(pm, cm);
+                        }
                     }
                     Acc sg = 0;
 #pragma unroll
@@ -2165,29 +2242,58 @@ int slice_cost_v3_impl(const QpCircuit* circ, const QpDTable* dt, const uint8_t*
             const bool gridpath = dt->kind == QP_DT_U16 && dt->grid.valid;
             const size_t strips = gstrips;
             const size_t tab256 = (size_t)dt->C * 256 * esz;
-            void (*kern)(V3Args) = nullptr;
-            size_t lds = strips;
+            // what the table takes in LDS and how it is addressed
+            int mode = kTabGlobal;
+            size_t tab_lds = 0;
             if (gridpath) {
                 if (int rc = fill_grid_args(q, dt)) return rc;
-                kern = (dt->grid.wrap_x || dt->grid.wrap_y) ? k_cost_v3_groups<QP_DT_U16, kTabGrid, true>
-                                                            : k_cost_v3_groups<QP_DT_U16, kTabGrid, false>;
+                mode = kTabGrid;
+            } else if (dt->C <= 16) {
+                // up to 16 cores: a 16-bit table 32 times, one copy per LDS bank: no look-up waits for another
+                // (fully random partitions: 1.5 -> 3.5 TB/s); an fp64 table 16 times (two lanes share a copy, but
+                // three 8-wave workgroups then fit a CU: 3.0 TB/s against 2.8 with 32 copies and one workgroup)
+                mode = kTabLdsRep4;
+                q.rep_shift = dt->kind == QP_DT_F64 ? 4 : 5;
+                tab_lds = ((size_t)256 << q.rep_shift) * (dt->kind == QP_DT_F64 ? 8 : 4);
+            } else if (dt->C <= 64) {
+                // up to 64 cores: the table at a pitch of 64 entries is 32 KB (fp64, or 16-bit twice), so three
+                // 8-wave workgroups fit a CU; more copies (up to 128 KB, one workgroup) measured no faster
+                mode = kTabLdsRep6;
+                q.rep_shift = dt->kind == QP_DT_F64 ? 0 : 1;
+                tab_lds = ((size_t)4096 << q.rep_shift) * (dt->kind == QP_DT_F64 ? 8 : 4);
             } else if (tab256 + strips <= (size_t)kLdsBytes) {
-                lds += tab256;
-                kern = dt->kind == QP_DT_F64 ? k_cost_v3_groups<QP_DT_F64, kTabLds256, false>
-                                             : k_cost_v3_groups<QP_DT_U16, kTabLds256, false>;
+                mode = kTabLds256;
+                tab_lds = tab256;
             } else if (tab_padded + strips <= (size_t)kLdsBytes) {
-                lds += tab_padded;
-                kern = dt->kind == QP_DT_F64 ? k_cost_v3_groups<QP_DT_F64, kTabLdsC, false>
-                                             : k_cost_v3_groups<QP_DT_U16, kTabLdsC, false>;
-            } else {
-                kern = dt->kind == QP_DT_F64 ? k_cost_v3_groups<QP_DT_F64, kTabGlobal, false>
-                                             : k_cost_v3_groups<QP_DT_U16, kTabGlobal, false>;
+                mode = kTabLdsC;
+                tab_lds = tab_padded;
             }
+            // workgroups of 8 waves when three or more of them fit a CU (24 waves or more in flight where one
+            // workgroup of 16 waves would be alone: the registers of this kernel allow 5 to 7 waves per SIMD)
+            const bool half = 3 * (tab_lds + strips / 2) <= (size_t)kLdsBytes;
+            const int threads = half ? kV3Threads / 2 : kV3Threads;
+            const size_t lds = tab_lds + (half ? strips / 2 : strips);
+            void (*kern)(V3Args) = nullptr;
+#define QP_GROUPS(KIND, MODE, WRAP) (half ? k_cost_v3_groups<KIND, MODE, WRAP, kV3Threads / 2> : k_cost_v3_groups<KIND, MODE, WRAP, kV3Threads>)
+#define QP_GROUPS_KIND(MODE) (dt->kind == QP_DT_F64 ? QP_GROUPS(QP_DT_F64, MODE, false) : QP_GROUPS(QP_DT_U16, MODE, false))
+            switch (mode) {
+                case kTabGrid:
+                    kern = (dt->grid.wrap_x || dt->grid.wrap_y) ? QP_GROUPS(QP_DT_U16, kTabGrid, true) : QP_GROUPS(QP_DT_U16, kTabGrid, false);
+                    break;
+                case kTabLdsRep4: kern = QP_GROUPS_KIND(kTabLdsRep4); break;
+                case kTabLdsRep6: kern = QP_GROUPS_KIND(kTabLdsRep6); break;
+                case kTabLds256: kern = QP_GROUPS_KIND(kTabLds256); break;
+                case kTabLdsC: kern = QP_GROUPS_KIND(kTabLdsC); break;
+                default: kern = QP_GROUPS_KIND(kTabGlobal); break;
+            }
+#undef QP_GROUPS_KIND
+#undef QP_GROUPS
+            const int waves = threads / kWave;
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             int per_cu = 1;
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), kV3Threads, lds));
-            const unsigned ggrid = (unsigned)std::min<int64_t>((int64_t)cus * std::max(per_cu, 1), (q.nitems + kV3Waves - 1) / kV3Waves);
-            kern<<<ggrid, kV3Threads, lds, stream>>>(q);
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), threads, lds));
+            const unsigned ggrid = (unsigned)std::min<int64_t>((int64_t)cus * std::max(per_cu, 1), (q.nitems + waves - 1) / waves);
+            kern<<<ggrid, threads, lds, stream>>>(q);
             HIP_TRY(hipGetLastError());
             k_sum_chunks<<<(unsigned)((B + 255) / 256), 256, 0, stream>>>(q.partial, B, gchunks, out);
             HIP_TRY(hipGetLastError());
