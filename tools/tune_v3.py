@@ -19,15 +19,17 @@ from quantum_simulator_amd.timeslices import CircuitIR  # noqa: E402
 
 def main():
     dev = torch.device("cuda", 0)
-    Q, T, B = 1024, 1000, 4096
+    Q, T = int(os.environ.get("QP_Q", "1024")), int(os.environ.get("QP_T", "1000"))
+    B = int(os.environ.get("QP_B", str(max(64, (1 << 32) // (((Q + 15) // 16 * 16) * T)))))  # default: about 4 GB
     q0, q1, _ = layered_gate_arrays(Q, T, 0.5, seed=2025)
     ir = CircuitIR.from_gate_tables(Q, q0, q1)
     dc, eng = DeviceCircuit(ir, dev), Engine(dev)
-    A = make_partitions(torch, dev, B, ir.T, Q, dc.ldq, 256, 8, float(os.environ.get("QP_PMOVE", "0.95")), seed=777)
+    A = make_partitions(torch, dev, B, ir.T, Q, dc.ldq, int(os.environ.get("QP_MESH", "16")) ** 2, 8, float(os.environ.get("QP_PMOVE", "0.95")), seed=777)
     out = torch.empty(B, dtype=torch.float64, device=dev)
     random.seed(1234)
     weights = (2.0, 2.0) if len(sys.argv) < 2 or sys.argv[1] == "integer" else (1.0, 3.0)
-    arch = multicore(16, 16, ncm_qubits=4, ncp_qubits=8, edge_weight_range=weights, network_type="mesh")
+    nx = int(os.environ.get("QP_MESH", "16"))
+    arch = multicore(nx, nx, ncm_qubits=4, ncp_qubits=8, edge_weight_range=weights, network_type="mesh")
     nodes, eu, ev, w = graph_tables(arch.network)
     dt = DistanceTable(apsp(len(nodes), eu, ev, w), dev)
     table = sys.argv[2] if len(sys.argv) > 2 else "packed"
