@@ -863,9 +863,12 @@ extern "C" int qp_place_sparse(int32_t which, int32_t T, int32_t Q, int32_t ldq,
         for (int32_t k = 0; k < nb_ptr[C]; ++k)
             if (nb[k] < 0 || nb[k] >= C) return qp::fail(QP_EINVAL, "qp_place_sparse: core index out of range");
     }
+    // Repeats that draw from one stream run one after another, as the calls they stand for would; repeats with a
+    // state each are independent and are dealt to host threads.
+    auto run_reps = [&](int32_t rep_begin, int32_t rep_end) {
     std::vector<int32_t> room((size_t)C), open_nodes, queue, start;
     std::vector<uint8_t> done((size_t)Q), seen((size_t)C);
-    for (int32_t rep = 0; rep < n_rep; ++rep) {
+    for (int32_t rep = rep_begin; rep < rep_end; ++rep) {
         PyRandom rng(mt_states + (size_t)(n_states == 1 ? 0 : rep) * 625);
         uint8_t* Ar = A_out + (size_t)rep * T * ldq;
         for (int32_t t = 0; t < T; ++t) {
@@ -957,6 +960,18 @@ extern "C" int qp_place_sparse(int32_t which, int32_t T, int32_t Q, int32_t ldq,
                 }
             }
         }
+    }
+    };
+    const int32_t workers = (n_states == n_rep && n_rep > 1)
+                                ? (int32_t)std::min<int64_t>({(int64_t)n_rep, 16, (int64_t)std::max(1u, std::thread::hardware_concurrency())})
+                                : 1;
+    if (workers <= 1) {
+        run_reps(0, n_rep);
+    } else {
+        std::vector<std::thread> pool;
+        for (int32_t w = 0; w < workers; ++w)
+            pool.emplace_back(run_reps, (int32_t)((int64_t)n_rep * w / workers), (int32_t)((int64_t)n_rep * (w + 1) / workers));
+        for (auto& th : pool) th.join();
     }
     return QP_OK;
 }

@@ -9,8 +9,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
-from conftest import case_arch, case_circuit, load_case  # noqa: E402
+from quantum_simulator_amd.golden import case_arch, case_circuit, load_case  # noqa: E402
 from quantum_simulator_amd.placers import PLACERS  # noqa: E402
 
 

@@ -6,9 +6,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
-from conftest import case_arch, case_circuit, load_case
+from quantum_simulator_amd.golden import case_arch, case_circuit, load_case
 from quantum_simulator_amd.placers import PLACERS
 name = sys.argv[1] if len(sys.argv) > 1 else "qft18_mesh4x4_u"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 256

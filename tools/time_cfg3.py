@@ -6,8 +6,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
-from conftest import load_case  # noqa: E402
+from quantum_simulator_amd.golden import load_case  # noqa: E402
 from quantum_simulator_amd import driver  # noqa: E402
 
 

@@ -8,8 +8,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
-from conftest import GOLDEN_INDEX, case_circuit, load_case  # noqa: E402
+from quantum_simulator_amd.golden import GOLDEN_INDEX, case_circuit, load_case  # noqa: E402
 from quantum_simulator_amd import circuit_to_qasm_str, driver  # noqa: E402
 
 PUBLISHED_S = {"RANDOM": 5.0229, "BFS": 5.5221, "TRHQA": 4.8258, "HQA": 5.3829, "GTRHQA": 4.7455}
