@@ -148,6 +148,8 @@ SHORT_ROWS = [  # Q, T, C, B, integer weights, pmove: rows of 16 to 512 bytes (1
     (512, 3, 256, 4, True, 1.0), (18, 138, 16, 700, False, 0.3),
     # fp64 tables too large for LDS on partitions of 32 KB or more: core pairs are counted
     (64, 500, 256, 4, False, 0.9), (512, 700, 144, 3, False, 0.4), (100, 5000, 180, 2, False, 0.05),
+    # ... and on shorter partitions: gathers from device memory
+    (60, 90, 150, 3, False, 0.5),
 ]
 
 
