@@ -161,6 +161,8 @@ struct V3Args {
     uint32_t table_bytes;
     int32_t band_lo, band_rows;
     int32_t rep_shift;  // kTabLdsRep*: log2 of the copies of every table entry (copy = lane & (copies - 1))
+    int32_t parts_per_item;  // k_cost_v3_groups: consecutive partitions a wave takes as one stream of steps (> 1 only
+    int64_t nbgroups;        // when an item is a whole partition), and how many such groups of partitions there are
     // grid metric (kTabGrid): byte-replicated masks of the x and y fields of a core id, the shift that
     // brings y down, half the ring length per byte for a dimension that wraps (0 = does not wrap), weights
     uint32_t gxm, gym, gxb, ghalfx, ghalfy, gwx, gwy;
@@ -446,52 +448,61 @@ __global__ __launch_bounds__(THREADS) void k_cost_v3_groups(V3Args p) {
     };
     const uint32_t* gsched_lane = p.gsched + lane;
 
+    const size_t pstride = (size_t)p.Tp * ldq;
     for (int64_t it = (int64_t)blockIdx.x * (THREADS / kWave) + wave; it < p.nitems; it += (int64_t)gridDim.x * (THREADS / kWave)) {
-        const int chunk = (int)(it / p.B);
-        const int64_t b = it - (int64_t)chunk * p.B;
+        // an item: a run of whole groups of slices (rows r0 .. r1 - 1) of np consecutive partitions; np > 1 only
+        // when the run is the whole circuit, and the wave then walks the partitions as one stream of steps, so
+        // that the loads of a partition's first steps are in flight while the one before it is finished
+        const int chunk = (int)(it / p.nbgroups);
+        const int64_t b0 = (it - (int64_t)chunk * p.nbgroups) * p.parts_per_item;
+        const int np = (int)min((int64_t)p.parts_per_item, p.B - b0);
         const int r0 = chunk * p.rows_per_item;  // a multiple of G
         const int r1 = min(p.T, r0 + p.rows_per_item);
         const int nsteps = (r1 - r0 + G - 1) / G;
-        const int j0 = r0 / G, jlast = j0 + nsteps - 1;
-        const uint8_t* base = p.A + (size_t)b * p.Tp * ldq;
+        const int j0 = r0 / G;
+        const int N = np * nsteps;
+        const uint8_t* base0 = p.A + (size_t)b0 * pstride;
         Acc acc = 0;
         uint32_t ax = 0, ay = 0;
         GridAcc gacc;
 
-        // the lane's piece of step s: rows past the item's end repeat its last row (never counted)
-        auto fetch_rows = [&](int s) -> uint4 {
-            const int rowl = min(r0 + s * G + lrow, r1 - 1);
-            return load_row16(base + ((uint32_t)rowl * (uint32_t)ldq + (uint32_t)lq0));
-        };
-        auto fetch_gate = [&](int s, int c) -> uint32_t {
-            const uint32_t* gp = gsched_lane + p.gptr[min(j0 + s, jlast)];  // wave-uniform + lane
-            return gp[c * kWave];
+        // the next step of the stream (partition fp, step fs): the lane's piece of its rows (rows past the run's end
+        // repeat its last row, never counted) and the first gate chunks of its group; past the end of the stream
+        // the last step is requested again
+        int fp = 0, fs = 0;
+        auto fetch_next = [&](uint4& rslot, uint32_t (&gslot)[kRowEdgeChunks]) {
+            const uint8_t* base = base0 + (size_t)fp * pstride;  // wave-uniform
+            const int rowl = min(r0 + fs * G + lrow, r1 - 1);
+            rslot = load_row16(base + ((uint32_t)rowl * (uint32_t)ldq + (uint32_t)lq0));
+            const uint32_t* gp = gsched_lane + p.gptr[j0 + fs];  // wave-uniform + lane
+#pragma unroll
+            for (int c = 0; c < kRowEdgeChunks; ++c) gslot[c] = gp[c * kWave];
+            if (fs + 1 < nsteps) {
+                ++fs;
+            } else if (fp + 1 < np) {
+                fs = 0;
+                ++fp;
+            }
         };
 
-        if (r0 >= 1 && lane < lpr)
+        if (r0 >= 1 && lane < lpr)  // (np == 1 here)
             *reinterpret_cast<uint4*>(strip + lane * 16) =
-                *reinterpret_cast<const uint4*>(base + (size_t)(r0 - 1) * ldq + lane * 16);
+                *reinterpret_cast<const uint4*>(base0 + (size_t)(r0 - 1) * ldq + lane * 16);
         uint4 ring[AHEAD];
         uint32_t gring[AHEAD][kRowEdgeChunks];
 #pragma unroll
-        for (int k = 0; k < AHEAD; ++k) {
-            ring[k] = fetch_rows(k);
-#pragma unroll
-            for (int c = 0; c < kRowEdgeChunks; ++c) gring[k][c] = fetch_gate(k, c);
-        }
+        for (int k = 0; k < AHEAD; ++k) fetch_next(ring[k], gring[k]);
 
-        for (int s0 = 0; s0 < nsteps; s0 += AHEAD) {
+        int cp = 0, s = 0;  // the step being worked on: partition cp of the item, step s
+        for (int n0 = 0; n0 < N; n0 += AHEAD) {
 #pragma unroll
             for (int k = 0; k < AHEAD; ++k) {
-                const int s = s0 + k;
-                if (s >= nsteps) break;
+                if (n0 + k >= N) break;
                 const uint4 cur = ring[k];
                 uint32_t gates[kRowEdgeChunks];
 #pragma unroll
                 for (int c = 0; c < kRowEdgeChunks; ++c) gates[c] = gring[k][c];
-                ring[k] = fetch_rows(s + AHEAD);
-#pragma unroll
-                for (int c = 0; c < kRowEdgeChunks; ++c) gring[k][c] = fetch_gate(s + AHEAD, c);
+                fetch_next(ring[k], gring[k]);
 
                 uint4 prv = make_uint4(0, 0, 0, 0);
                 if (lane_on) {
@@ -578,13 +589,22 @@ __global__ __launch_bounds__(THREADS) void k_cost_v3_groups(V3Args p) {
                 }
                 // the group's last row is "the row before" of the next step
                 if (last_row) *reinterpret_cast<uint4*>(strip + lq0) = cur;
+                if (s + 1 < nsteps) {
+                    ++s;
+                } else {  // the partition's run is done: its sum, and a fresh start for the next partition
+                    double sum;
+                    if constexpr (TABMODE != kTabGrid) sum = wave_sum(acc);
+                    else if constexpr (WRAP) sum = gacc.total(p);
+                    else sum = (double)p.gwx * wave_sum(ax) + (double)p.gwy * (wave_sum(ay) / (double)(1u << p.gxb));
+                    if (lane == 0) p.partial[(size_t)chunk * p.B + b0 + cp] = sum;
+                    acc = 0;
+                    ax = ay = 0;
+                    gacc = GridAcc();
+                    s = 0;
+                    ++cp;
+                }
             }
         }
-        double sum;
-        if constexpr (TABMODE != kTabGrid) sum = wave_sum(acc);
-        else if constexpr (WRAP) sum = gacc.total(p);
-        else sum = (double)p.gwx * wave_sum(ax) + (double)p.gwy * (wave_sum(ay) / (double)(1u << p.gxb));
-        if (lane == 0) p.partial[it] = sum;
     }
 }
 
@@ -2219,7 +2239,13 @@ int slice_cost_v3_impl(const QpCircuit* circ, const QpDTable* dt, const uint8_t*
         const int64_t spi = std::min<int64_t>(steps_total, std::min<int64_t>(256, std::max<int64_t>(8, want)));
         q.rows_per_item = (int)(spi * G);
         const int32_t gchunks = (T + q.rows_per_item - 1) / q.rows_per_item;
-        q.nitems = (int64_t)gchunks * B;
+        // a circuit of few steps: several consecutive partitions per item (up to 256 steps), walked as one stream,
+        // as long as that leaves a few items for every wave the GPU holds
+        q.parts_per_item = 1;
+        if (gchunks == 1)
+            q.parts_per_item = (int)std::max<int64_t>(1, std::min<int64_t>({256 / steps_total, 64, B / ((int64_t)cus * 24 * 2)}));
+        q.nbgroups = (B + q.parts_per_item - 1) / q.parts_per_item;
+        q.nitems = (int64_t)gchunks * q.nbgroups;
         const size_t gstrips = (size_t)kV3Waves * (G + 1) * ldq;
         if (dt->kind == QP_DT_F64 && dt->symmetric && dt->C >= 2 && tab_padded + gstrips > (size_t)kLdsBytes &&
             (int64_t)T * ldq >= 32768) {
@@ -2248,7 +2274,7 @@ int slice_cost_v3_impl(const QpCircuit* circ, const QpDTable* dt, const uint8_t*
                 return QP_OK;
             }
         }
-        if (workspace_bytes >= (size_t)q.nitems * sizeof(double)) {
+        if (workspace_bytes >= (size_t)gchunks * B * sizeof(double)) {
             const bool gridpath = dt->kind == QP_DT_U16 && dt->grid.valid;
             const size_t strips = gstrips;
             const size_t tab256 = (size_t)dt->C * 256 * esz;

@@ -195,6 +195,31 @@ def test_cost_v3_short_rows_in_groups(gpu, Q, T, C, B, integer, pmove):
         assert all(_close(again[b], got[b], integer, nterms) for b in range(B)), (again, got)
 
 
+@pytest.mark.parametrize("Q,T,C,B,integer", [(18, 40, 16, 30000, False), (100, 70, 64, 26000, True), (40, 300, 9, 25000, True)])
+def test_cost_v3_many_short_partitions(gpu, Q, T, C, B, integer):
+    """Tens of thousands of partitions of a circuit of few steps: a wave then walks several consecutive partitions
+    as one stream.  Every partition must cost, bit for bit, what it costs in a batch small enough for one
+    partition per item, and a sample of them what the vectorised CPU sum says."""
+    from oracle.cpu_variants import NumpyCost
+    torch, engine, eng, dev = gpu
+    ir, eu, ev, w, rng = _random_setup(Q, T, C, integer, seed=Q * 17 + T)
+    D = engine.apsp(C, eu, ev, w)
+    dc, dt = engine.DeviceCircuit(ir, dev), engine.DistanceTable(D, dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(Q * T)
+    A = torch.randint(0, C, (B, ir.T, dc.ldq), device=dev, generator=g, dtype=torch.int16).to(torch.uint8)
+    keep = torch.rand((B, ir.T, dc.ldq), device=dev, generator=g) < 0.6
+    for t in range(1, ir.T):
+        A[:, t] = torch.where(keep[:, t], A[:, t - 1], A[:, t])
+    got = eng.cost_v3(dc, dt, A).cpu().numpy()
+    small = torch.cat([eng.cost_v3(dc, dt, A[i:i + 1000].contiguous()) for i in range(0, B, 1000)]).cpu().numpy()
+    assert got.tobytes() == small.tobytes()
+    nc = NumpyCost(ir.slices, ir.gate_q, ir.gate_mr, D)
+    for b in list(range(5)) + [int(x) for x in rng.integers(0, B, size=40)] + [B - 1]:
+        want = nc.cost(A[b, :, :Q].cpu().numpy())
+        assert _close(got[b], want, integer, ir.nE + ir.T * Q), (b, got[b], want)
+
+
 GROUPED = [  # Q, T, C, B, integer weights: rows over 512 bytes, table in LDS at pitch 256, 64 partitions or more
     (1000, 70, 256, 67, True), (1024, 9, 64, 64, False), (600, 41, 40, 130, False), (513, 3, 200, 65, True),
     (777, 2, 64, 66, False), (1024, 1, 256, 64, True),
