@@ -347,7 +347,7 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3(V3Args p) {
 // with nothing else to do, is a small part of it.  TABMODE: kTabLds256, kTabLdsC, kTabGlobal, or kTabGrid (no table;
 // WRAP = some dimension of the grid is a ring).
 template <int KIND, int TABMODE, bool WRAP, int THREADS = kV3Threads, int AHEAD = kV3Ahead>
-__global__ __launch_bounds__(THREADS) void k_cost_v3_groups(V3Args p) {
+__global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void k_cost_v3_groups(V3Args p) {
     extern __shared__ __align__(16) uint8_t smem[];
     using E = typename Tab<KIND>::elem;
     using Acc = typename Tab<KIND>::acc;
