@@ -570,10 +570,14 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void k_cost_v3_gro
                             if (pm != cm) acc += four(pm, cm);
                         }
                     }
-                    Acc sg = 0;
+                    // a lane whose four gates all have both qubits on one core (what a placer works for) looks
+                    // nothing up
+                    if (((au[0] ^ av[0]) | (au[1] ^ av[1]) | (au[2] ^ av[2]) | (au[3] ^ av[3])) != 0) {
+                        Acc sg = 0;
 #pragma unroll
-                    for (int c = 0; c < kRowEdgeChunks; ++c) sg += pair_at(au[c], av[c]);
-                    acc += sg;
+                        for (int c = 0; c < kRowEdgeChunks; ++c) sg += pair_at(au[c], av[c]);
+                        acc += sg;
+                    }
                 }
                 for (int c = kRowEdgeChunks; c < nch; ++c) {
                     const uint32_t g = gsched_lane[w0 + c * kWave];
@@ -789,7 +793,8 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_row(V3Args p) {
                         if (c3 != p3) acc += four(p3, c3);
                     }
                 }
-                {
+                // a lane whose four gates all have both qubits on one core (what a placer works for) looks nothing up
+                if (((au[0] ^ av[0]) | (au[1] ^ av[1]) | (au[2] ^ av[2]) | (au[3] ^ av[3])) != 0) {
                     Acc s = 0;
 #pragma unroll
                     for (int c = 0; c < kRowEdgeChunks; ++c) s += pair_at(au[c], av[c]);

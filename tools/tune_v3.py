@@ -25,6 +25,13 @@ def main():
     ir = CircuitIR.from_gate_tables(Q, q0, q1)
     dc, eng = DeviceCircuit(ir, dev), Engine(dev)
     A = make_partitions(torch, dev, B, ir.T, Q, dc.ldq, int(os.environ.get("QP_MESH", "16")) ** 2, 8, float(os.environ.get("QP_PMOVE", "0.95")), seed=777)
+    if os.environ.get("QP_SATISFY"):  # what a placer's output looks like: both qubits of every gate on one core
+        eu = torch.from_numpy(ir.edge_u.astype("int64")).to(dev)
+        ev = torch.from_numpy(ir.edge_v.astype("int64")).to(dev)
+        sep = ir.slice_edge_ptr
+        for t in range(ir.T):
+            u, v = eu[sep[t]:sep[t + 1]], ev[sep[t]:sep[t + 1]]
+            A[:, t, v] = A[:, t, u]
     out = torch.empty(B, dtype=torch.float64, device=dev)
     random.seed(1234)
     weights = (2.0, 2.0) if len(sys.argv) < 2 or sys.argv[1] == "integer" else (1.0, 3.0)
