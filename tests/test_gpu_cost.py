@@ -195,7 +195,7 @@ def test_cost_v3_short_rows_in_groups(gpu, Q, T, C, B, integer, pmove):
         assert all(_close(again[b], got[b], integer, nterms) for b in range(B)), (again, got)
 
 
-@pytest.mark.parametrize("Q,T,C,B,integer", [(18, 40, 16, 30000, False), (100, 70, 64, 26000, True), (40, 300, 9, 25000, True)])
+@pytest.mark.parametrize("Q,T,C,B,integer", [(18, 40, 16, 50001, False), (100, 70, 64, 26001, True), (40, 300, 9, 25000, True)])
 def test_cost_v3_many_short_partitions(gpu, Q, T, C, B, integer):
     """Tens of thousands of partitions of a circuit of few steps: a wave then walks several consecutive partitions
     as one stream.  Every partition must cost, bit for bit, what it costs in a batch small enough for one
