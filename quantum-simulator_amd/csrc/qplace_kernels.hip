@@ -131,6 +131,8 @@ constexpr int kTabPairs = 5;   // no look-ups: unordered core pairs are counted 
 // ------------------------------------------------------------------------------------------------
 // Cost V3: dense partitions, HQA-family definition.
 //
+// k_cost_v3 is the form for rows of at most 512 bytes when the caller gives no grouped gate list (with one,
+// k_cost_v3_groups below does the same work about three times as fast).
 // Work item = (timeslice chunk, partition); item id = chunk * B + b so that the workgroups running
 // at one time read the same part of the circuit's edge list (it stays in L2) while each streams its
 // own contiguous rows of A.  One wave owns an item: it walks the rows in groups of G = 64*16/ldq rows
