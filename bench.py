@@ -497,6 +497,23 @@ def main():
             fl = torch.tensor([cm["entries_per_s"]], dtype=torch.float64, device=dev)
             dist.all_reduce(fl, op=dist.ReduceOp.SUM)
             cm["entries_per_s"] = float(fl.item())
+    activity = None
+    if not args.no_qubo:
+        # per-core inter-core activity counts (HQA_placer.py:288-321) of the same partitions, a slice of the batch
+        nb = min(B, 1024)
+        Asub = A[:nb]
+        eng.core_activity(dc, Asub, C)
+        torch.cuda.synchronize(dev)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(torch.cuda.current_stream(dev))
+        for _ in range(5):
+            counts = eng.core_activity(dc, Asub, C)
+        ev1.record(torch.cuda.current_stream(dev))
+        torch.cuda.synchronize(dev)
+        ms = ev0.elapsed_time(ev1) / 5
+        activity = {"kernel": "k_core_activity", "partitions": nb, "kernel_ms": ms, "evals_per_s": nb * ir.T / (ms * 1e-3),
+                    "gbs": nb * ir.T * dc.ldq / (ms * 1e-3) / 1e9, "events_in_partition_0": int(counts[0].sum().item())}
+        del Asub, counts
     qubo = None
     if not args.no_qubo:
         del A
@@ -539,7 +556,7 @@ def main():
                        "seeds": {"circuit": circ_seed, "weights": weight_seed, "partitions": "777+rank"},
                        "table": primary["table"]},
             "roofline": primary["roofline"], "mean_cost": primary["mean_cost"], "min_cost": primary["min_cost"],
-            "reduce_ms": primary["reduce_ms"], "gtrhqa_place": place, "cost_matrix": cm, "qubo": qubo,
+            "reduce_ms": primary["reduce_ms"], "gtrhqa_place": place, "cost_matrix": cm, "core_activity": activity, "qubo": qubo,
             "shipped_circuits": shipped, "shipped_circuits_cost_at_scale": shipped_cost, "broken_links": broken,
         }
         # HBM bytes per launch as measured with rocprofv3 PMC counters in a separate run of this workload

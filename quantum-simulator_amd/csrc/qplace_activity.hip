@@ -95,7 +95,8 @@ __global__ __launch_bounds__(kThreads) void k_comm_matrix(const uint8_t* A, cons
 
 extern "C" int qp_core_activity(const QpCircuit* circ, const uint8_t* A, int64_t B, int32_t Tp, int32_t ldq, int32_t C,
                                 uint64_t* out, void* stream_) {
-    if (!circ || !A || !out) return qp::fail(QP_EINVAL, "qp_core_activity: null argument");
+    // (a circuit without slices has partitions without rows: nothing to read, every count is zero)
+    if (!circ || (!A && circ->T > 0) || !out) return qp::fail(QP_EINVAL, "qp_core_activity: null argument");
     if (B <= 0 || B > 65535) return qp::fail(QP_EINVAL, "qp_core_activity: B must be 1..65535 per call");
     if (C <= 0 || C > 256) return qp::fail(QP_EINVAL, "qp_core_activity: bad core count");
     if (circ->Q <= 0 || ldq < circ->Q) return qp::fail(QP_EINVAL, "qp_core_activity: bad row pitch");
@@ -113,7 +114,7 @@ extern "C" int qp_core_activity(const QpCircuit* circ, const uint8_t* A, int64_t
 
 extern "C" int qp_comm_matrix(const QpCircuit* circ, const uint8_t* A, int64_t B, int32_t Tp, int32_t ldq, int32_t C,
                               int32_t* out, int32_t* status, void* stream_) {
-    if (!circ || !A || !out || !status) return qp::fail(QP_EINVAL, "qp_comm_matrix: null argument");
+    if (!circ || (!A && circ->T > 0) || !out || !status) return qp::fail(QP_EINVAL, "qp_comm_matrix: null argument");
     if (B <= 0 || B > 65535) return qp::fail(QP_EINVAL, "qp_comm_matrix: B must be 1..65535 per call");
     if (C <= 0 || C > 255) return qp::fail(QP_EINVAL, "qp_comm_matrix: bad core count");
     if (circ->Q <= 0 || ldq < circ->Q) return qp::fail(QP_EINVAL, "qp_comm_matrix: bad row pitch");

@@ -138,8 +138,12 @@ def test_cost_v3_random(gpu, Q, T, C, B, integer):
     got = eng.cost_v3(dc, dt, torch.from_numpy(A).to(dev)).cpu().numpy()
     Dl = D.tolist()
     for b in range(B):
+        # 1e-12 against the correctly rounded sum; against the reference's left-to-right sum its own error bound
+        # counts too once there are tens of thousands of terms (two cores: every term is the same number)
+        terms = O.cost_v3_terms(ir.slices, ir.gate_q, ir.gate_mr, A[b, :, :Q].tolist(), Dl)
+        assert _close(got[b], math.fsum(terms), integer), (b, got[b], math.fsum(terms))
         want = O.cost_v3(ir.slices, ir.gate_q, ir.gate_mr, A[b, :, :Q].tolist(), Dl)
-        assert _close(got[b], want, integer), (b, got[b], want)
+        assert _close(got[b], want, integer, len(terms)), (b, got[b], want)
 
 
 SHORT_ROWS = [  # Q, T, C, B, integer weights, pmove: rows of 16 to 512 bytes (1 to 32 pieces, 64 to 2 rows per wave step)
@@ -634,6 +638,11 @@ def test_degenerate_circuits(gpu):
     A = torch.from_numpy(rng.integers(0, C, size=(2, 3, dc.ldq), dtype=np.uint8)).to(dev)
     assert eng.cost_v3(dc, dt, A).cpu().tolist() == [0.0, 0.0]
     assert eng.cost_v2(dc, dt, A, engine.QP_V2).cpu().tolist() == [0.0, 0.0]
+    # partitions of a circuit without slices have no rows at all: the counts are zero, not an error
+    none = torch.empty((2, 0, dc.ldq), dtype=torch.uint8, device=dev)
+    assert int(eng.core_activity(dc, none, C).sum().item()) == 0
+    M, status = eng.comm_matrix(dc, none, C)
+    assert int(M.sum().item()) == 0 and int(status.sum().item()) == 0
     assert eng.core_activity(dc, A, C).cpu().numpy().sum() == 0
     init = torch.from_numpy(rng.integers(0, C, size=(2, dc.ldq), dtype=np.uint8)).to(dev)
     rows = eng.gtrhqa_place(dc, dt, init, cap)
