@@ -511,7 +511,7 @@ def main():
         ev1.record(torch.cuda.current_stream(dev))
         torch.cuda.synchronize(dev)
         ms = ev0.elapsed_time(ev1) / 5
-        activity = {"kernel": "k_core_activity", "partitions": nb, "kernel_ms": ms, "evals_per_s": nb * ir.T / (ms * 1e-3),
+        activity = {"kernel": "k_cost_v3_pairs<4, true>" if 512 < dc.ldq <= 1024 else "k_core_activity", "partitions": nb, "kernel_ms": ms, "evals_per_s": nb * ir.T / (ms * 1e-3),
                     "gbs": nb * ir.T * dc.ldq / (ms * 1e-3) / 1e9, "events_in_partition_0": int(counts[0].sum().item())}
         del Asub, counts
     qubo = None

@@ -24,6 +24,12 @@ int cost_matrix_resolved(int32_t kind, const double* tables, int32_t C, const in
                          const int16_t* resolved, const int32_t* n_ops, int32_t max_ops, const uint8_t* avail,
                          const int32_t* n_avail, double* cost_out, void* stream);
 
+// qp_core_activity through the pair counters of the dense cost kernels (rows of 513 to 1024 bytes, per-slice gate
+// list present): adds the counts to out[B][C], which the caller has zeroed.  QP_OK, a negative code, or 1 when
+// this form does not apply.  Device translation units only.
+int core_activity_pairs(const QpCircuit* circ, const uint8_t* A, int64_t B, int32_t Tp, int32_t ldq, int32_t C,
+                        uint64_t* out, void* stream);
+
 // The make-space step of qp_make_space on one assignment row and its occupancy counts.
 void make_space_row(uint8_t* a, int64_t* occ, int32_t Q, int32_t C, int32_t cap, const double* D);
 }  // namespace qp

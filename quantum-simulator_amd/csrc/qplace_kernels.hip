@@ -163,6 +163,7 @@ struct V3Args {
     uint32_t table_bytes;
     int32_t band_lo, band_rows;
     int32_t rep_shift;  // kTabLdsRep*: log2 of the copies of every table entry (copy = lane & (copies - 1))
+    unsigned long long* activity;  // k_cost_v3_pairs<., true>: per-core event counts [B][C] instead of a cost
     int32_t parts_per_item;  // k_cost_v3_groups: consecutive partitions a wave takes as one stream of steps (> 1 only
     int64_t nbgroups;        // when an item is a whole partition), and how many such groups of partitions there are
     // grid metric (kTabGrid): byte-replicated masks of the x and y fields of a core id, the shift that
@@ -1100,7 +1101,28 @@ __device__ inline double apply_pair_counts(uint32_t* cnt, const double* fold) {
     return acc;
 }
 
-template <int AHEAD = kV3Ahead>
+// The same pass for the per-core activity (HQA_placer.py:288-321: every move and every gate across two cores is one
+// event for each of the two cores): a pair's count goes to both of its cores in hist[256], diagonal slots (a qubit
+// that stayed, a gate inside one core) to nobody.  Slot k of the folded rectangle is row k >> 8, column k & 255:
+// pair (128 + row, column) up to the diagonal, pair (127 - row, 255 - column) beyond it (see k_sym_fold).
+template <int THREADS>
+__device__ inline void apply_pair_activity(uint32_t* cnt, uint32_t* hist) {
+    for (int k = threadIdx.x; k < kPairSlots; k += THREADS) {
+        const uint32_t n = cnt[k];
+        if (n) {
+            cnt[k] = 0;
+            const int r = k >> 8, col = k & 255;
+            const bool upper = col <= 128 + r;
+            const int hi = upper ? 128 + r : 127 - r, lo = upper ? col : 255 - col;
+            if (hi != lo) {
+                atomicAdd(&hist[hi], n);
+                atomicAdd(&hist[lo], n);
+            }
+        }
+    }
+}
+
+template <int AHEAD = kV3Ahead, bool ACTIVITY = false>
 __global__ __launch_bounds__(kV3Threads) void k_cost_v3_pairs(V3Args p) {
     extern __shared__ __align__(16) uint8_t smem[];
     const int lane = threadIdx.x & (kWave - 1);
@@ -1113,7 +1135,9 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_pairs(V3Args p) {
     double* red = reinterpret_cast<double*>(smem + (size_t)kPairSlots * 4 + (size_t)kV3Waves * ldq);
     const uint32_t cbase = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_u8*)smem - 0x20000u);
     const double* fold = static_cast<const double*>(p.table);
+    uint32_t* hist = reinterpret_cast<uint32_t*>(red + kV3Waves);  // ACTIVITY: events per core
     for (int k = threadIdx.x; k < kPairSlots; k += kV3Threads) cnt[k] = 0;
+    if (ACTIVITY && threadIdx.x < 256) hist[threadIdx.x] = 0;
     __syncthreads();
 
     const bool lane_on = lane * 16 < ldq;
@@ -1218,7 +1242,7 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_pairs(V3Args p) {
                     const uint32_t u = strip[g & 0xFFFFu], v = strip[g >> 16];
                     count_gates2(u, v);  // the upper halves are the pair (0, 0): a diagonal slot
                 }
-                if (row >= 2) {  // movement is charged from row 2 on; a dword of qubits that all stayed is skipped
+                if (row >= (ACTIVITY ? 1 : 2)) {  // movement is charged from row 2 on (events are counted from row 1 on); a dword of qubits that all stayed is skipped
                     if (c0 != p0) count4(p0, c0);
                     if (c1 != p1) count4(p1, c1);
                     if (c2 != p2) count4(p2, c2);
@@ -1241,6 +1265,17 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_pairs(V3Args p) {
                 if (g0 + k < w1) do_row(g0 + k, ring[k], gring[k], sring[k], ering[k], false);
         }
         __syncthreads();
+        if constexpr (ACTIVITY) {
+            apply_pair_activity<kV3Threads>(cnt, hist);
+            __syncthreads();
+            if (threadIdx.x < 256) {
+                const uint32_t n = hist[threadIdx.x];
+                hist[threadIdx.x] = 0;
+                if (n && (int)threadIdx.x < p.C) atomicAdd(&p.activity[(size_t)b * p.C + threadIdx.x], (unsigned long long)n);
+            }
+            __syncthreads();  // hist is zero again before the next item's pass adds to it
+            continue;
+        }
         double acc = apply_pair_counts<kV3Threads>(cnt, fold);
         acc = wave_sum(acc);
         if (lane == 0) red[wave] = acc;
@@ -2392,7 +2427,7 @@ int slice_cost_v3_impl(const QpCircuit* circ, const QpDTable* dt, const uint8_t*
                 k_sym_fold<<<kPairSlots / 256, 256, 0, stream>>>(static_cast<const double*>(dt->table), dt->C, fold);
                 HIP_TRY(hipGetLastError());
                 q.table = fold;
-                kern = k_cost_v3_pairs<kV3Ahead>;
+                kern = k_cost_v3_pairs<kV3Ahead, false>;
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pairs_lds));
                 const unsigned pgrid = (unsigned)std::min<int64_t>(cus, q.nitems);
                 kern<<<pgrid, kV3Threads, pairs_lds, stream>>>(q);
@@ -2523,6 +2558,40 @@ int static_scratch(void** out) {
 }
 
 }  // namespace
+
+// Per-core activity counts through the pair counters (rows of 513 to 1024 bytes with the per-slice gate list):
+// QP_OK when the launch was made, 1 when this form does not apply and the caller should use its own kernel.
+int qp::core_activity_pairs(const QpCircuit* circ, const uint8_t* A, int64_t B, int32_t Tp, int32_t ldq, int32_t C,
+                            uint64_t* out, void* stream_) {
+    const int32_t T = circ->T;
+    if (ldq <= 512 || ldq > 1024 || ldq % 16 || !circ->edges_sched || !circ->sched_ptr || circ->nE <= 0 || T <= 0 ||
+        reinterpret_cast<uintptr_t>(A) % 16)
+        return 1;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    V3Args q{};
+    q.A = A;
+    q.edges_sched = circ->edges_sched;
+    q.sptr = circ->sched_ptr;
+    q.B = B;
+    q.T = T;
+    q.Tp = Tp;
+    q.ldq = ldq;
+    q.Q = circ->Q;
+    q.C = C;
+    q.activity = reinterpret_cast<unsigned long long*>(out);
+    const int cus = qp::device_cus();
+    const int64_t want = ((int64_t)T * B + (int64_t)cus * 8 - 1) / ((int64_t)cus * 8);
+    q.rows_per_item = (int)std::min<int64_t>(T, std::max<int64_t>(4 * kV3Waves, (want + kV3Waves - 1) / kV3Waves * kV3Waves));
+    const int32_t chunks = (T + q.rows_per_item - 1) / q.rows_per_item;
+    q.nitems = (int64_t)chunks * B;
+    const size_t lds = (size_t)kPairSlots * sizeof(uint32_t) + (size_t)kV3Waves * ldq + kV3Waves * sizeof(double) + 256 * sizeof(uint32_t);
+    if (lds > (size_t)kLdsBytes) return 1;
+    void (*kern)(V3Args) = k_cost_v3_pairs<kV3Ahead, true>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    kern<<<(unsigned)std::min<int64_t>(cus, q.nitems), kV3Threads, lds, stream>>>(q);
+    HIP_TRY(hipGetLastError());
+    return QP_OK;
+}
 
 extern "C" int qp_slice_cost_v3(const QpCircuit* circ, const QpDTable* dt, const uint8_t* A, int64_t B, int32_t Tp,
                                 int32_t ldq, double* out, void* workspace, size_t workspace_bytes, void* stream) {
