@@ -421,7 +421,7 @@ def main():
         elif table == "packed" and dt.symmetric:
             how = ("f64, 512 KB (too large for LDS), symmetric to rounding: core pairs are counted in LDS "
                    "(uint32 per unordered pair), one product with the table per partition")
-            kname = "k_cost_v3_pairs<4>"
+            kname = "k_cost_v3_pairs<4, false>"
         else:
             how, kname = "f64, 512 KB: LDS-resident in 4 bands of source cores, one pass per band", "k_cost_v3_row<0, 3, 4> x4"
         # untimed: about 0.3 s of the same launches first, so that a box that has just been idle is at its

@@ -6,7 +6,7 @@ import json
 import sys
 
 tag = sys.argv[1]
-KERNEL = {"uniform": "k_cost_v3_pairs<4>", "integer": "k_cost_v3_grid_row<false, 4>",
+KERNEL = {"uniform": "k_cost_v3_pairs<4, false>", "integer": "k_cost_v3_grid_row<false, 4>",
           "integer_table": "k_cost_v3_row4<1, 4>"}
 out = {}
 for w, kernel in KERNEL.items():
