@@ -105,7 +105,7 @@ extern "C" int qp_core_activity(const QpCircuit* circ, const uint8_t* A, int64_t
     HIP_TRY(hipMemsetAsync(out, 0, (size_t)B * C * sizeof(uint64_t), stream));
     if (circ->T == 0) return QP_OK;
     if (!circ->slice_edge_ptr || (circ->nE > 0 && !circ->edges)) return qp::fail(QP_EINVAL, "qp_core_activity: circuit edge tables missing");
-    // rows of 513 to 1024 bytes: the events are the row and column sums of the core-pair counts the dense cost
+    // rows of up to 1024 bytes (partitions of 32 KB or more when shorter than 513): the events are the row and column sums of the core-pair counts the dense cost
     // kernel forms (one LDS atomic per moved qubit where the kernel below needs two on 256 counters)
     if (const int rc = qp::core_activity_pairs(circ, A, B, Tp, ldq, C, out, stream_); rc <= 0) return rc;
     const dim3 grid((unsigned)((circ->T + kRowsPerBlock - 1) / kRowsPerBlock), (unsigned)B);

@@ -24,8 +24,8 @@ int cost_matrix_resolved(int32_t kind, const double* tables, int32_t C, const in
                          const int16_t* resolved, const int32_t* n_ops, int32_t max_ops, const uint8_t* avail,
                          const int32_t* n_avail, double* cost_out, void* stream);
 
-// qp_core_activity through the pair counters of the dense cost kernels (rows of 513 to 1024 bytes, per-slice gate
-// list present): adds the counts to out[B][C], which the caller has zeroed.  QP_OK, a negative code, or 1 when
+// qp_core_activity through the pair counters of the dense cost kernels (rows of 513 to 1024 bytes with the per-slice
+// gate list, shorter rows with the grouped one when a partition is 32 KB or more): adds the counts to out[B][C], which the caller has zeroed.  QP_OK, a negative code, or 1 when
 // this form does not apply.  Device translation units only.
 int core_activity_pairs(const QpCircuit* circ, const uint8_t* A, int64_t B, int32_t Tp, int32_t ldq, int32_t C,
                         uint64_t* out, void* stream);

@@ -1293,7 +1293,7 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_pairs(V3Args p) {
 // The same for rows of at most 512 bytes (grouped gate list, G rows per wave step as in k_cost_v3_groups): the
 // item's steps are dealt to the workgroup's waves in runs, every wave parks its steps in its own strip
 // [row before][G rows] and counts into the shared counters.
-template <int AHEAD = kV3Ahead>
+template <int AHEAD = kV3Ahead, bool ACTIVITY = false>
 __global__ __launch_bounds__(kV3Threads) void k_cost_v3_pairs_groups(V3Args p) {
     extern __shared__ __align__(16) uint8_t smem[];
     const int lane = threadIdx.x & (kWave - 1);
@@ -1305,7 +1305,9 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_pairs_groups(V3Args p) {
     double* red = reinterpret_cast<double*>(smem + (size_t)kPairSlots * 4 + (size_t)kV3Waves * (G + 1) * ldq);
     const uint32_t cbase = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_u8*)smem - 0x20000u);
     const double* fold = static_cast<const double*>(p.table);
+    uint32_t* hist = reinterpret_cast<uint32_t*>(red + kV3Waves);  // ACTIVITY: events per core
     for (int k = threadIdx.x; k < kPairSlots; k += kV3Threads) cnt[k] = 0;
+    if (ACTIVITY && threadIdx.x < 256) hist[threadIdx.x] = 0;
     __syncthreads();
 
     const bool lane_on = lane < G * lpr;
@@ -1391,7 +1393,7 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_pairs_groups(V3Args p) {
                     }
                     // movement: rows 2 .. r1 - 1; everything else compares a piece with itself and is skipped
                     const int row = rw + s * G + lrow;
-                    const bool mv = row >= 2 && row < r1;
+                    const bool mv = row >= (ACTIVITY ? 1 : 2) && row < r1;  // (events are counted from row 1 on)
                     const uint32_t cw[4] = {cur.x, cur.y, cur.z, cur.w};
                     const uint32_t pw[4] = {mv ? prv.x : cur.x, mv ? prv.y : cur.y, mv ? prv.z : cur.z, mv ? prv.w : cur.w};
 #pragma unroll
@@ -1404,6 +1406,17 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_pairs_groups(V3Args p) {
             }
         }
         __syncthreads();
+        if constexpr (ACTIVITY) {
+            apply_pair_activity<kV3Threads>(cnt, hist);
+            __syncthreads();
+            if (threadIdx.x < 256) {
+                const uint32_t n = hist[threadIdx.x];
+                hist[threadIdx.x] = 0;
+                if (n && (int)threadIdx.x < p.C) atomicAdd(&p.activity[(size_t)b * p.C + threadIdx.x], (unsigned long long)n);
+            }
+            __syncthreads();
+            continue;
+        }
         double acc = wave_sum(apply_pair_counts<kV3Threads>(cnt, fold));
         if (lane == 0) red[wave] = acc;
         __syncthreads();
@@ -2307,7 +2320,7 @@ int slice_cost_v3_impl(const QpCircuit* circ, const QpDTable* dt, const uint8_t*
                 k_sym_fold<<<kPairSlots / 256, 256, 0, stream>>>(static_cast<const double*>(dt->table), dt->C, fold);
                 HIP_TRY(hipGetLastError());
                 c.table = fold;
-                void (*kern)(V3Args) = k_cost_v3_pairs_groups<kV3Ahead>;
+                void (*kern)(V3Args) = k_cost_v3_pairs_groups<kV3Ahead, false>;
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)clds));
                 kern<<<(unsigned)std::min<int64_t>(cus, c.nitems), kV3Threads, clds, stream>>>(c);
                 HIP_TRY(hipGetLastError());
@@ -2559,19 +2572,26 @@ int static_scratch(void** out) {
 
 }  // namespace
 
-// Per-core activity counts through the pair counters (rows of 513 to 1024 bytes with the per-slice gate list):
+// Per-core activity counts through the pair counters (rows of 513 to 1024 bytes with the per-slice gate list, shorter
+// rows with the grouped one and partitions of 32 KB or more):
 // QP_OK when the launch was made, 1 when this form does not apply and the caller should use its own kernel.
 int qp::core_activity_pairs(const QpCircuit* circ, const uint8_t* A, int64_t B, int32_t Tp, int32_t ldq, int32_t C,
                             uint64_t* out, void* stream_) {
     const int32_t T = circ->T;
-    if (ldq <= 512 || ldq > 1024 || ldq % 16 || !circ->edges_sched || !circ->sched_ptr || circ->nE <= 0 || T <= 0 ||
-        reinterpret_cast<uintptr_t>(A) % 16)
-        return 1;
+    if (ldq < 16 || ldq > 1024 || ldq % 16 || circ->nE <= 0 || T <= 0 || reinterpret_cast<uintptr_t>(A) % 16) return 1;
+    const bool rows_1k = ldq > 512;
+    if (rows_1k ? (!circ->edges_sched || !circ->sched_ptr)
+                : (!circ->group_sched || !circ->group_ptr || circ->group_ldq != ldq || (int64_t)T * ldq < 32768))
+        return 1;  // (short partitions: a pass over all counters per item costs more than it saves)
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     V3Args q{};
     q.A = A;
     q.edges_sched = circ->edges_sched;
     q.sptr = circ->sched_ptr;
+    q.gsched = circ->group_sched;
+    q.gptr = circ->group_ptr;
+    q.lpr = ldq / 16;
+    q.G = rows_1k ? 1 : kWave / q.lpr;
     q.B = B;
     q.T = T;
     q.Tp = Tp;
@@ -2580,13 +2600,24 @@ int qp::core_activity_pairs(const QpCircuit* circ, const uint8_t* A, int64_t B, 
     q.C = C;
     q.activity = reinterpret_cast<unsigned long long*>(out);
     const int cus = qp::device_cus();
-    const int64_t want = ((int64_t)T * B + (int64_t)cus * 8 - 1) / ((int64_t)cus * 8);
-    q.rows_per_item = (int)std::min<int64_t>(T, std::max<int64_t>(4 * kV3Waves, (want + kV3Waves - 1) / kV3Waves * kV3Waves));
+    size_t strips;
+    void (*kern)(V3Args);
+    if (rows_1k) {
+        const int64_t want = ((int64_t)T * B + (int64_t)cus * 8 - 1) / ((int64_t)cus * 8);
+        q.rows_per_item = (int)std::min<int64_t>(T, std::max<int64_t>(4 * kV3Waves, (want + kV3Waves - 1) / kV3Waves * kV3Waves));
+        strips = (size_t)kV3Waves * ldq;
+        kern = k_cost_v3_pairs<kV3Ahead, true>;
+    } else {  // whole groups of G slices per item, as the cost launch forms them
+        const int64_t steps_total = (T + q.G - 1) / q.G;
+        const int64_t want = (steps_total * B + (int64_t)cus * 8 - 1) / ((int64_t)cus * 8);
+        q.rows_per_item = (int)(std::min<int64_t>(steps_total, std::max<int64_t>(2 * kV3Waves, want)) * q.G);
+        strips = (size_t)kV3Waves * (q.G + 1) * ldq;
+        kern = k_cost_v3_pairs_groups<kV3Ahead, true>;
+    }
     const int32_t chunks = (T + q.rows_per_item - 1) / q.rows_per_item;
     q.nitems = (int64_t)chunks * B;
-    const size_t lds = (size_t)kPairSlots * sizeof(uint32_t) + (size_t)kV3Waves * ldq + kV3Waves * sizeof(double) + 256 * sizeof(uint32_t);
+    const size_t lds = (size_t)kPairSlots * sizeof(uint32_t) + strips + kV3Waves * sizeof(double) + 256 * sizeof(uint32_t);
     if (lds > (size_t)kLdsBytes) return 1;
-    void (*kern)(V3Args) = k_cost_v3_pairs<kV3Ahead, true>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     kern<<<(unsigned)std::min<int64_t>(cus, q.nitems), kV3Threads, lds, stream>>>(q);
     HIP_TRY(hipGetLastError());

@@ -283,7 +283,7 @@ def test_core_activity_matches_reference_fixture():
 
 
 @pytest.mark.parametrize("Q,T,C,B", [(40, 30, 8, 4), (200, 70, 64, 3), (1024, 130, 256, 2), (33, 1, 5, 2), (700, 300, 200, 5),
-                                     (1000, 2, 17, 3), (513, 1, 100, 2)])
+                                     (1000, 2, 17, 3), (513, 1, 100, 2), (200, 400, 64, 3), (63, 600, 16, 2), (17, 2100, 5, 3)])
 def test_core_activity_and_comm_matrix_random(Q, T, C, B):
     import torch
     from oracle import placer_oracle as O

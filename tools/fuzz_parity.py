@@ -149,7 +149,7 @@ def main():
         if kind == 6:  # rows longer than 1 KB: one or four 16-byte pieces per thread, one or several chunks of rows
             Q = pick(16385, 24000) if pick(0, 5) == 0 else pick(1025, 6000)
             T = pick(1, max(1, min(600, 1200000 // Q)))
-            topo, nx, ny = [("mesh", pick(1, 16), pick(1, 16)), ("torus", pick(3, 16), pick(3, 16)), ("line", pick(2, 200), 1),
+            topo, nx, ny = [("mesh", pick(1, 16), pick(2, 16)), ("torus", pick(3, 16), pick(3, 16)), ("line", pick(2, 200), 1),  # (two cores or more: one core has no distances)
                             ("star", pick(3, 60), 1), ("all_to_all", pick(2, 6), pick(1, 6))][pick(0, 4)]
             wt = float(pick(1, 5)) if pick(0, 1) else 0
             return "cost_v3_wide_rows", TC.test_cost_v3_wide_rows, (gpu, Q, T, topo, nx, ny, wt, pick(1, 3), float(rng.choice([0.02, 0.3, 1.0])))
