@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define QP_VERSION 202
+#define QP_VERSION 203
 
 #define QP_OK 0
 #define QP_EINVAL (-1)   /* bad argument (shape, alignment, range) */
@@ -83,6 +83,12 @@ typedef struct QpCircuit {
                                        into those rows, padded like edges_sched); the dense cost kernels for short
                                        rows read this list when the partitions' row pitch equals group_ldq */
     const int32_t* group_ptr;       /* [ceil(T / qp_group_rows(group_ldq)) + 1] start of every group (required with it) */
+    const uint8_t* visit_mask;      /* optional, rows of 513 to 1024 bytes: [T][visit_mask_ldq] bytes, 0xFF where the
+                                       qubit is an operand of some command of the slice (a visit of the gate-ordered
+                                       walk), 0 elsewhere and in the padding; with it and edges_sched, large batches
+                                       of the gate-ordered cost are walked row by row instead of visit by visit */
+    int32_t visit_mask_ldq;         /* row pitch visit_mask was laid out for; 0 = none */
+    int32_t reserved_;
 } QpCircuit;
 
 /* Distance table as the kernels consume it. */

@@ -24,7 +24,8 @@ class QpCircuit(C.Structure):
                 ("max_slice_edges", C.c_int32), ("group_ldq", C.c_int32),
                 ("slice_edge_ptr", C.c_void_p), ("edges", C.c_void_p), ("lookahead", C.c_void_p),
                 ("slice_visit_ptr", C.c_void_p), ("visits", C.c_void_p), ("edges_sched", C.c_void_p), ("sched_ptr", C.c_void_p),
-                ("group_sched", C.c_void_p), ("group_ptr", C.c_void_p)]
+                ("group_sched", C.c_void_p), ("group_ptr", C.c_void_p),
+                ("visit_mask", C.c_void_p), ("visit_mask_ldq", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class QpGridMetric(C.Structure):

@@ -1950,6 +1950,158 @@ __global__ __launch_bounds__(THREADS) void k_cost_v2(V2Args p) {
     }
 }
 
+// Cost V2 / V4 as a row walk, for circuits that visit most qubits in most slices (rows of 513 to 1024 bytes, 16-bit
+// table).  One wave owns a partition and reads its rows once, 16 bytes per lane; the core every qubit had at its last
+// visit stays in four registers per lane (0xFF = not visited yet, or on no core then).  vmask holds, per slice, 0xFF in
+// the bytes of the qubits the slice visits, so
+//     from = (vmask & last) | (~vmask & row)    equals the row wherever nothing is visited,
+//     last = (vmask & row)  | (~vmask & last)   afterwards,
+// and the movement term of the whole row is the packed look-up of (from, row) pairs the dense kernels use: pairs of
+// equal cores read the zero diagonal.  The table is staged at pitch 256 with row and column 255 zero, so a qubit
+// without a previous core adds nothing; the cases the reference fails on (a visited qubit that has a previous core
+// but no current one, a counted gate with an operand on no core: inf in the results) are found by byte tests and
+// end in inf.  Gates come from the per-slice list of the dense kernels, (first operand | second << 16), padding words
+// zero.  Sums are integers: flushed into 64 bits every few rows.
+struct V2WalkArgs {
+    const uint8_t* A;
+    const uint8_t* vmask;
+    const uint32_t* sched;
+    const int32_t* sptr;
+    const void* table;
+    double* out;
+    int64_t B;
+    int32_t T, Tp, ldq, C;
+};
+
+template <bool V4, int AHEAD>
+__global__ __launch_bounds__(kV3Threads) void k_cost_v2_walk(V2WalkArgs p) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    using E = uint16_t;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    {
+        const E* src = static_cast<const E*>(p.table);
+        E* dst = reinterpret_cast<E*>(smem);
+        for (int k = threadIdx.x; k < 256 * 256; k += blockDim.x) {
+            const int r = k >> 8, c = k & 255;
+            dst[k] = (r < p.C && c < p.C) ? src[r * p.C + c] : E(0);
+        }
+        __syncthreads();
+    }
+    const E* tab = reinterpret_cast<const E*>(smem);
+    const uint32_t tbase = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_u8*)smem);
+    const int ldq = p.ldq;
+    uint8_t* strip = smem + 256 * 256 * sizeof(E) + (size_t)wave * ldq;
+    const bool lane_on = lane * 16 < ldq;
+    const int lane16 = lane_on ? lane * 16 : 0;
+    const uint32_t lane_mask = lane_on ? ~0u : 0u;
+    auto four = [&](uint32_t from, uint32_t to) -> uint32_t {
+        E e0, e1, e2, e3;
+        entries_at_halves<E>(__builtin_amdgcn_perm(from, to, 0x05010400u), tbase, e0, e1);
+        entries_at_halves<E>(__builtin_amdgcn_perm(from, to, 0x07030602u), tbase, e2, e3);
+        return ((uint32_t)e0 + e1) + ((uint32_t)e2 + e3);
+    };
+    // non-zero iff some byte of y is 0xFF
+    auto any_ff = [](uint32_t y) -> uint32_t { return (~y - 0x01010101u) & y & 0x80808080u; };
+    // a visited byte (m) that is 0xFF in the row (c) but not in the last cores (l)
+    auto lost = [](uint32_t m, uint32_t l, uint32_t c) -> bool {
+        int n = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            n += (((m >> (8 * j)) & 0xFFu) != 0 && ((c >> (8 * j)) & 0xFFu) == 0xFFu && ((l >> (8 * j)) & 0xFFu) != 0xFFu) ? 1 : 0;
+        return n != 0;
+    };
+    const uint32_t* sched_lane = p.sched + lane;
+    const int T = p.T;
+
+    for (int64_t b = (int64_t)blockIdx.x * kV3Waves + wave; b < p.B; b += (int64_t)gridDim.x * kV3Waves) {
+        const uint8_t* base = p.A + (size_t)b * p.Tp * ldq;
+        auto fetch_row = [&](int row) -> uint4 { return load_row16(base + (size_t)min(row, T - 1) * ldq + lane16); };
+        auto fetch_mask = [&](int row) -> uint4 {  // lanes past the end of the row visit nothing
+            const uint4 m = *reinterpret_cast<const uint4*>(p.vmask + (size_t)min(row, T - 1) * ldq + lane16);
+            return make_uint4(m.x & lane_mask, m.y & lane_mask, m.z & lane_mask, m.w & lane_mask);
+        };
+        auto fetch_gate = [&](int row, int c) -> uint32_t { return sched_lane[p.sptr[min(row, T - 1)] + c * kWave]; };
+        uint32_t l0 = ~0u, l1 = ~0u, l2 = ~0u, l3 = ~0u;
+        unsigned long long total = 0;
+        bool bad = false;
+        uint4 ring[AHEAD], mring[AHEAD];
+        uint32_t gring[AHEAD][kRowEdgeChunks];
+#pragma unroll
+        for (int k = 0; k < AHEAD; ++k) {
+            ring[k] = fetch_row(k);
+            mring[k] = fetch_mask(k);
+#pragma unroll
+            for (int c = 0; c < kRowEdgeChunks; ++c) gring[k][c] = fetch_gate(k, c);
+        }
+        for (int g0 = 0; g0 < T; g0 += AHEAD) {
+            uint32_t acc = 0;  // at most AHEAD * (16 + gates of a slice / 64 + 1) terms below 2^16 each
+#pragma unroll
+            for (int k = 0; k < AHEAD; ++k) {
+                const int row = g0 + k;
+                if (row >= T) break;
+                const uint4 cur = ring[k], vm = mring[k];
+                uint32_t gates[kRowEdgeChunks];
+#pragma unroll
+                for (int c = 0; c < kRowEdgeChunks; ++c) gates[c] = gring[k][c];
+                ring[k] = fetch_row(row + AHEAD);
+                mring[k] = fetch_mask(row + AHEAD);
+#pragma unroll
+                for (int c = 0; c < kRowEdgeChunks; ++c) gring[k][c] = fetch_gate(row + AHEAD, c);
+
+                if (lane_on) *reinterpret_cast<uint4*>(strip + lane * 16) = cur;
+                const int s0 = p.sptr[row];
+                const int nch = (p.sptr[row + 1] - s0) / kWave;
+                uint32_t au[kRowEdgeChunks], av[kRowEdgeChunks];
+#pragma unroll
+                for (int c = 0; c < kRowEdgeChunks; ++c) {
+                    if (c >= nch) gates[c] = 0u;  // (qubit 0, qubit 0): one core twice, distance zero
+                    au[c] = strip[gates[c] & 0xFFFFu];
+                    av[c] = strip[gates[c] >> 16];
+                }
+                // movement of the visited qubits
+                const uint32_t f0 = (vm.x & l0) | (~vm.x & cur.x), f1 = (vm.y & l1) | (~vm.y & cur.y);
+                const uint32_t f2 = (vm.z & l2) | (~vm.z & cur.z), f3 = (vm.w & l3) | (~vm.w & cur.w);
+                if (f0 != cur.x) acc += V4 ? four(cur.x, f0) : four(f0, cur.x);
+                if (f1 != cur.y) acc += V4 ? four(cur.y, f1) : four(f1, cur.y);
+                if (f2 != cur.z) acc += V4 ? four(cur.z, f2) : four(f2, cur.z);
+                if (f3 != cur.w) acc += V4 ? four(cur.w, f3) : four(f3, cur.w);
+                if ((any_ff(cur.x & vm.x) | any_ff(cur.y & vm.y) | any_ff(cur.z & vm.z) | any_ff(cur.w & vm.w)) != 0)
+                    bad = bad || lost(vm.x, l0, cur.x) || lost(vm.y, l1, cur.y) || lost(vm.z, l2, cur.z) || lost(vm.w, l3, cur.w);
+                l0 = (vm.x & cur.x) | (~vm.x & l0);
+                l1 = (vm.y & cur.y) | (~vm.y & l1);
+                l2 = (vm.z & cur.z) | (~vm.z & l2);
+                l3 = (vm.w & cur.w) | (~vm.w & l3);
+                // the slice's gates
+                uint32_t top = 0;
+#pragma unroll
+                for (int c = 0; c < kRowEdgeChunks; ++c) top = max(top, max(au[c], av[c]));
+                if (top == 0xFFu) {
+#pragma unroll
+                    for (int c = 0; c < kRowEdgeChunks; ++c) bad = bad || (gates[c] != 0u && max(au[c], av[c]) == 0xFFu);
+                }
+                if (((au[0] ^ av[0]) | (au[1] ^ av[1]) | (au[2] ^ av[2]) | (au[3] ^ av[3])) != 0) {
+                    uint32_t s = 0;
+#pragma unroll
+                    for (int c = 0; c < kRowEdgeChunks; ++c) s += tab[(au[c] << 8) | av[c]];
+                    acc += s;
+                }
+                for (int c = kRowEdgeChunks; c < nch; ++c) {
+                    const uint32_t g = sched_lane[s0 + c * kWave];
+                    const uint32_t cu = strip[g & 0xFFFFu], cv = strip[g >> 16];
+                    bad = bad || (g != 0u && max(cu, cv) == 0xFFu);
+                    acc += tab[(cu << 8) | cv];
+                }
+            }
+            total += acc;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off, kWave);
+        const bool any_bad = __builtin_amdgcn_ballot_w64(bad) != 0;
+        if (lane == 0) p.out[b] = any_bad ? std::numeric_limits<double>::infinity() : (double)total;
+    }
+}
+
 __global__ void k_fill(double* out, int64_t n, double v) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = v;
@@ -2663,6 +2815,30 @@ extern "C" int qp_slice_cost_v2(const QpCircuit* circ, const QpDTable* dt, const
     }
     if (T == 0 || circ->nV == 0) {
         k_fill<<<(unsigned)((B + 255) / 256), 256, 0, stream>>>(out, B, 0.0);
+        HIP_TRY(hipGetLastError());
+        return QP_OK;
+    }
+    // Many partitions of a circuit that visits most of every row (over 128 qubits a slice, where reading whole rows
+    // beats gathering the visited bytes): the row walk.  16-bit tables only: its sums are integers.
+    if (flags != QP_V1 && dt->kind == QP_DT_U16 && ldq > 512 && ldq <= 1024 && B >= 1024 && circ->visit_mask &&
+        circ->visit_mask_ldq == ldq && circ->edges_sched && circ->sched_ptr && (int64_t)circ->nV >= (int64_t)128 * T) {
+        V2WalkArgs w{};
+        w.A = A;
+        w.vmask = circ->visit_mask;
+        w.sched = circ->edges_sched;
+        w.sptr = circ->sched_ptr;
+        w.table = dt->table;
+        w.out = out;
+        w.B = B;
+        w.T = T;
+        w.Tp = Tp;
+        w.ldq = ldq;
+        w.C = dt->C;
+        void (*walk)(V2WalkArgs) = flags == QP_V4 ? k_cost_v2_walk<true, kV3Ahead> : k_cost_v2_walk<false, kV3Ahead>;
+        const size_t lds = (size_t)256 * 256 * sizeof(uint16_t) + (size_t)kV3Waves * ldq;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(walk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const unsigned grid = (unsigned)std::min<int64_t>(qp::device_cus(), (B + kV3Waves - 1) / kV3Waves);
+        walk<<<grid, kV3Threads, lds, stream>>>(w);
         HIP_TRY(hipGetLastError());
         return QP_OK;
     }

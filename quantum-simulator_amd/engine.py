@@ -106,7 +106,7 @@ def lsap_batch(costs: np.ndarray, nr: np.ndarray, nc: np.ndarray, threads: int =
 class DeviceCircuit:
     """A CircuitIR uploaded once; ``.c`` is the QpCircuit the ABI takes."""
 
-    def __init__(self, ir: CircuitIR, device=None):
+    def __init__(self, ir: CircuitIR, device=None, visit_mask=True):
         self.ir = ir
         self.device = device if device is not None else default_device()
         if ir.Q > 32767:
@@ -125,12 +125,17 @@ class DeviceCircuit:
         self._gsched = self._gptr = None
         if grouped is not None:
             self._gptr, self._gsched = _to_dev(grouped[0], self.device), _to_dev(grouped[1], self.device)
+        # rows of 513 to 1024 bytes: which qubits every slice visits, for the row walk of the gate-ordered cost
+        # (visit_mask=False leaves it out: the cost is then always taken visit by visit)
+        self._vmask = _to_dev(ir.visit_mask(self.ldq), self.device) if visit_mask and 512 < self.ldq <= 1024 and ir.T else None
         self.c = QpCircuit(ir.Q, ir.T, ir.nE, ir.nV, most, self.ldq if grouped is not None else 0,
                            self._sep.data_ptr(), self._edges.data_ptr(),
                            self._la.data_ptr(), self._svp.data_ptr(), self._visits.data_ptr(),
                            self._sched.data_ptr(), self._sched_ptr.data_ptr(),
                            self._gsched.data_ptr() if grouped is not None else None,
-                           self._gptr.data_ptr() if grouped is not None else None)
+                           self._gptr.data_ptr() if grouped is not None else None,
+                           self._vmask.data_ptr() if self._vmask is not None else None,
+                           self.ldq if self._vmask is not None else 0, 0)
 
     @property
     def csr_bytes(self):

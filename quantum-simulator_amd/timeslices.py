@@ -303,6 +303,14 @@ class CircuitIR:
                                                 _lib.ptr(sched), n))
         return sptr, sched
 
+    def visit_mask(self, ldq: int) -> np.ndarray:
+        """uint8 [T, ldq]: 0xFF where the qubit is an operand of a command of the slice (what the gate-ordered cost
+        loops visit, BFS_placer.py:214-237), 0 elsewhere."""
+        vm = np.zeros((self.T, int(ldq)), np.uint8)
+        if self.nV:
+            vm[self.visit_records["t"], self.visit_records["q"]] = 0xFF
+        return vm
+
     def grouped_edges(self, ldq: int):
         """(group_ptr, words) for partitions with rows of ``ldq`` <= 512 bytes, or None when the rows are longer:
         the counted gates of every ``64 // (ldq // 16)`` consecutive slices together, endpoints as byte offsets

@@ -449,6 +449,66 @@ def test_cost_v2_random(gpu, Q, T, C, B, integer):
         assert _close(got[0], want, integer)
 
 
+@pytest.mark.parametrize("Q,T,C,B,drop", [(1024, 37, 255, 1024, 0.05), (1000, 21, 16, 1100, 0.3), (600, 50, 100, 1030, 0.0),
+                                           (513, 9, 2, 1024, 0.2), (777, 130, 64, 1024, 0.1)])
+def test_cost_v2_row_walk(gpu, Q, T, C, B, drop):
+    """Large batches on a circuit that visits most qubits in most slices are walked row by row (16-bit tables): equal to
+    the visit-by-visit kernel on every partition and to the oracle on a sample, absent qubits and the errors they cause
+    included."""
+    from quantum_simulator_amd import layered_gate_arrays
+    from quantum_simulator_amd.timeslices import CircuitIR
+    torch, engine, eng, dev = gpu
+    rng = np.random.default_rng(Q + T)
+    q0, q1, _ = layered_gate_arrays(Q, T, 0.7, seed=Q + T)
+    keep = rng.random(len(q0)) >= drop
+    ir = CircuitIR.from_gate_tables(Q, q0[keep], q1[keep])
+    assert ir.nV >= 128 * ir.T
+    eu = list(range(C - 1)) + [int(x) for x in rng.integers(0, C, size=C)]
+    ev = list(range(1, C)) + [int(x) for x in rng.integers(0, C, size=C)]
+    ok = [k for k in range(len(eu)) if eu[k] != ev[k]]
+    eu, ev = [eu[k] for k in ok], [ev[k] for k in ok]
+    D = engine.apsp(C, eu, ev, rng.integers(1, 9, size=len(eu)).astype(float))
+    H = engine.hops(C, eu, ev)
+    walk, byvisit = engine.DeviceCircuit(ir, dev), engine.DeviceCircuit(ir, dev, visit_mask=False)
+    assert walk.c.visit_mask and not byvisit.c.visit_mask
+    dt, ht = engine.DistanceTable(D, dev), engine.DistanceTable(H, dev)
+    assert dt.kind == engine.QP_DT_U16
+    Tp = ir.T + (Q % 2)
+    A = rng.integers(0, C, size=(B, Tp, walk.ldq), dtype=np.uint8)
+    A[:, :, Q:] = rng.integers(0, 256, size=(B, Tp, walk.ldq - Q), dtype=np.uint8)
+    # qubits that stay where they are most of the time, as a placer leaves them
+    stay = rng.random((B, Tp, Q)) < 0.6
+    for t in range(1, Tp):
+        A[:, t, :Q] = np.where(stay[:, t], A[:, t - 1, :Q], A[:, t, :Q])
+    # partitions 0..39: only the visited qubits are placed; 40..59: some unvisited ones are absent;
+    # 60..79: a visited qubit is absent somewhere (an error unless it had no core before and is alone in its gate)
+    vm = ir.visit_mask(walk.ldq)[:, :Q] != 0
+    for b in range(40):
+        A[b, :ir.T, :Q][~vm] = 0xFF
+    for b in range(40, 60):
+        hole = (rng.random((ir.T, Q)) < 0.1) & ~vm
+        A[b, :ir.T, :Q][hole] = 0xFF
+    for b in range(60, 80):
+        v = ir.visit_records[int(rng.integers(0, ir.nV))]
+        A[b, v["t"], v["q"]] = 0xFF
+        if b >= 70:  # from the first slice on: no previous core either
+            A[b, :v["t"], v["q"]] = 0xFF
+    Ad = torch.from_numpy(A).to(dev)
+    Dl, Hl = D.tolist(), H.tolist()
+    for variant, fn, tab, tabl in ((engine.QP_V2, O.cost_v2, dt, Dl), (engine.QP_V4, O.cost_v4, ht, Hl)):
+        got = eng.cost_v2(walk, tab, Ad, variant).cpu().numpy()
+        ref = eng.cost_v2(byvisit, tab, Ad, variant).cpu().numpy()
+        assert got.tobytes() == ref.tobytes(), (variant, np.flatnonzero(got != ref)[:8])
+        assert np.isinf(got[60:80]).any() and np.isfinite(got[:60]).all()
+        for b in (0, 41, 60, 65, 70, 75, 79, B - 1):
+            rows = [[None if c == 0xFF else int(c) for c in r[:Q]] for r in A[b, :ir.T]]
+            try:
+                want = float(fn(ir.slices, ir.gate_q, ir.gate_mr, rows, tabl))
+            except O.CostError:
+                want = float("inf")
+            assert got[b] == want, (variant, b, got[b], want)
+
+
 def test_cost_v3_rejects_bad_arguments(gpu):
     torch, engine, eng, dev = gpu
     ir, eu, ev, w, rng = _random_setup(20, 5, 4, True, seed=1)

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in qplace.h but not exported"
     assert declared == set(_lib.EXPORTS), "ctypes table and header disagree"
-    assert _lib.lib().qp_version() == 202
+    assert _lib.lib().qp_version() == 203
 
 
 @pytest.mark.parametrize("name", ALL_CASES)
