@@ -89,6 +89,10 @@ typedef struct QpCircuit {
                                        of the gate-ordered cost are walked row by row instead of visit by visit */
     int32_t visit_mask_ldq;         /* row pitch visit_mask was laid out for; 0 = none */
     int32_t reserved_;
+    const int16_t* visit_prev;      /* optional with visit_mask, T <= 32767: [T][visit_mask_ldq], the last slice before
+                                       slice t that visits the qubit, -1 if none; lets the walk start in the middle of
+                                       a partition (small batches split into chunks of slices, fp64 tables counted
+                                       by core pair) */
 } QpCircuit;
 
 /* Distance table as the kernels consume it. */

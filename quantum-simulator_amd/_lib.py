@@ -25,7 +25,8 @@ class QpCircuit(C.Structure):
                 ("slice_edge_ptr", C.c_void_p), ("edges", C.c_void_p), ("lookahead", C.c_void_p),
                 ("slice_visit_ptr", C.c_void_p), ("visits", C.c_void_p), ("edges_sched", C.c_void_p), ("sched_ptr", C.c_void_p),
                 ("group_sched", C.c_void_p), ("group_ptr", C.c_void_p),
-                ("visit_mask", C.c_void_p), ("visit_mask_ldq", C.c_int32), ("reserved_", C.c_int32)]
+                ("visit_mask", C.c_void_p), ("visit_mask_ldq", C.c_int32), ("reserved_", C.c_int32),
+                ("visit_prev", C.c_void_p)]
 
 
 class QpGridMetric(C.Structure):

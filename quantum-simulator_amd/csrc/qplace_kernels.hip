@@ -164,6 +164,8 @@ struct V3Args {
     int32_t band_lo, band_rows;
     int32_t rep_shift;  // kTabLdsRep*: log2 of the copies of every table entry (copy = lane & (copies - 1))
     unsigned long long* activity;  // k_cost_v3_pairs<., true>: per-core event counts [B][C] instead of a cost
+    const uint8_t* vmask;          // k_cost_v2_pairs: [T][ldq] 0xFF where a slice visits the qubit
+    const int16_t* vprev;          // k_cost_v2_pairs: [T][ldq] last slice before t that visits the qubit, -1 if none
     int32_t parts_per_item;  // k_cost_v3_groups: consecutive partitions a wave takes as one stream of steps (> 1 only
     int64_t nbgroups;        // when an item is a whole partition), and how many such groups of partitions there are
     // grid metric (kTabGrid): byte-replicated masks of the x and y fields of a core id, the shift that
@@ -1122,8 +1124,45 @@ __device__ inline void apply_pair_activity(uint32_t* cnt, uint32_t* hist) {
     }
 }
 
-template <int AHEAD = kV3Ahead, bool ACTIVITY = false>
-__global__ __launch_bounds__(kV3Threads) void k_cost_v3_pairs(V3Args p) {
+// Helpers of the row walk of the gate-ordered cost (k_cost_v2_walk, k_cost_v2_pairs).
+// non-zero iff some byte of y is 0xFF
+__device__ inline uint32_t bytes_ff(uint32_t y) { return (~y - 0x01010101u) & y & 0x80808080u; }
+// a visited byte (mask m) that is 0xFF in the row (c) but not among the last cores (l): a qubit that had a core and
+// now has none, which the reference cannot price
+__device__ inline bool walk_lost(uint32_t m, uint32_t l, uint32_t c) {
+    int n = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        n += (((m >> (8 * j)) & 0xFFu) != 0 && ((c >> (8 * j)) & 0xFFu) == 0xFFu && ((l >> (8 * j)) & 0xFFu) != 0xFFu) ? 1 : 0;
+    return n != 0;
+}
+// The cores the lane's 16 qubits (row bytes lane16 .. lane16 + 15) had at their last visit before slice r0, from
+// vprev[r0][q] = that slice or -1; 0xFF where there was none.  Sixteen byte gathers per lane, all in flight together.
+__device__ inline void walk_state_at(const uint8_t* base, const int16_t* vprev, int r0, int ldq, int lane16, uint32_t (&st)[4]) {
+    st[0] = st[1] = st[2] = st[3] = ~0u;
+    if (r0 == 0) return;
+    const uint4* pr = reinterpret_cast<const uint4*>(vprev + (size_t)r0 * ldq + lane16);
+    const uint4 a = pr[0], b = pr[1];
+    const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    uint32_t got[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int r = (int)(int16_t)(w[j / 2] >> (16 * (j & 1)));
+        got[j] = base[(size_t)max(r, 0) * ldq + lane16 + j];
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int r = (int)(int16_t)(w[j / 2] >> (16 * (j & 1)));
+        const uint32_t v = r >= 0 ? got[j] : 0xFFu;
+        st[j / 4] = (st[j / 4] & ~(0xFFu << (8 * (j & 3)))) | (v << (8 * (j & 3)));
+    }
+}
+
+// WALK: the gate-ordered cost (V2 / V4, which differ only in the table the caller passes once it is symmetrised)
+// instead of the dense one: movement of the qubits a slice visits against their cores at their previous visit (see
+// k_cost_v2_walk), from the first row on; a wave's run starts from the state walk_state_at gathers.
+template <int AHEAD, bool ACTIVITY, bool WALK>
+__device__ __forceinline__ void pairs_by_row(const V3Args& p) {
     extern __shared__ __align__(16) uint8_t smem[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
@@ -1141,6 +1180,7 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_pairs(V3Args p) {
     __syncthreads();
 
     const bool lane_on = lane * 16 < ldq;
+    const uint32_t lane_mask = lane_on ? ~0u : 0u;
     const int nvalid_row = min(16, max(0, p.Q - lane * 16));
     uint32_t keep[4];
 #pragma unroll
@@ -1159,10 +1199,15 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_pairs(V3Args p) {
         // runs that differ by at most one row: every wave reaches the barrier at about the same time
         const int w0 = r0 + (r1 - r0) * wave / kV3Waves, w1 = r0 + (r1 - r0) * (wave + 1) / kV3Waves;
         const uint8_t* base = p.A + (size_t)b * p.Tp * ldq;
+        bool bad = false;  // WALK: a case the reference fails on
         if (w0 < w1) {
             const int lane16 = lane_on ? lane * 16 : 0;
             const uint32_t* sched_lane = p.edges_sched + lane;
             auto fetch_row = [&](int row) -> uint4 { return load_row16(base + (size_t)min(row, w1 - 1) * ldq + lane16); };
+            auto fetch_mask = [&](int row) -> uint4 {  // WALK: the bytes of the qubits the slice visits
+                const uint4 m = *reinterpret_cast<const uint4*>(p.vmask + (size_t)min(row, w1 - 1) * ldq + lane16);
+                return make_uint4(m.x & lane_mask, m.y & lane_mask, m.z & lane_mask, m.w & lane_mask);
+            };
             // Slice starts in the gate list.  The barriers of this kernel keep the compiler from reading them
             // through the scalar cache, and as wave-uniform vector loads it would move each result to a
             // scalar register at once, draining every prefetch issued before it.  So they are loaded through
@@ -1174,14 +1219,21 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_pairs(V3Args p) {
             auto slice_start = [&](int row) -> int { return p.sptr[min(row, w1) + opaque_zero]; };
             auto fetch_gate = [&](int start, int c) -> uint32_t { return sched_lane[start + c * kWave]; };
             uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
-            if (w0 >= 1) {
+            if constexpr (WALK) {
+                uint32_t st[4];
+                walk_state_at(base, p.vprev, w0, ldq, lane16, st);
+                p0 = st[0];
+                p1 = st[1];
+                p2 = st[2];
+                p3 = st[3];
+            } else if (w0 >= 1) {
                 const uint4 prv = fetch_row(w0 - 1);
                 p0 = prv.x & keep[0];
                 p1 = prv.y & keep[1];
                 p2 = prv.z & keep[2];
                 p3 = prv.w & keep[3];
             }
-            uint4 ring[AHEAD];
+            uint4 ring[AHEAD], mring[WALK ? AHEAD : 1];
             uint32_t gring[AHEAD][kRowEdgeChunks];
             int sring[AHEAD], ering[AHEAD];
             int sp_next = slice_start(w0);
@@ -1191,13 +1243,16 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_pairs(V3Args p) {
                 sp_next = slice_start(w0 + k + 1);
                 ering[k] = sp_next;
                 ring[k] = fetch_row(w0 + k);
+                if constexpr (WALK) mring[k] = fetch_mask(w0 + k);
                 const int start = __builtin_amdgcn_readfirstlane(sring[k]);
 #pragma unroll
                 for (int c = 0; c < kRowEdgeChunks; ++c) gring[k][c] = fetch_gate(start, c);
             }
             // one row: consume slot k of the ring, refill it with row + AHEAD (REFILL), count the row's pairs
-            auto do_row = [&](int row, uint4& rslot, uint32_t (&gslot)[kRowEdgeChunks], int& sslot, int& eslot, bool refill) {
+            auto do_row = [&](int row, uint4& rslot, uint4& mslot, uint32_t (&gslot)[kRowEdgeChunks], int& sslot, int& eslot, bool refill) {
                 const uint4 cur = rslot;
+                uint4 vm = make_uint4(0, 0, 0, 0);
+                if constexpr (WALK) vm = mslot;
                 const int s0 = __builtin_amdgcn_readfirstlane(sslot);
                 const int nch = (__builtin_amdgcn_readfirstlane(eslot) - s0) / kWave;
                 uint32_t gates[kRowEdgeChunks];
@@ -1209,6 +1264,7 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_pairs(V3Args p) {
                     sslot = sp_here;
                     eslot = sp_next;
                     rslot = fetch_row(row + AHEAD);
+                    if constexpr (WALK) mslot = fetch_mask(row + AHEAD);
                     const int start = __builtin_amdgcn_readfirstlane(sp_here);
 #pragma unroll
                     for (int c = 0; c < kRowEdgeChunks; ++c) gslot[c] = fetch_gate(start, c);
@@ -1241,6 +1297,33 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_pairs(V3Args p) {
                     const uint32_t g = sched_lane[s0 + c * kWave];
                     const uint32_t u = strip[g & 0xFFFFu], v = strip[g >> 16];
                     count_gates2(u, v);  // the upper halves are the pair (0, 0): a diagonal slot
+                    if constexpr (WALK) bad = bad || (g != 0u && max(u, v) == 0xFFu);
+                }
+                if constexpr (WALK) {
+                    // a counted gate (padding words are zero) with an operand on no core
+                    uint32_t top = 0;
+#pragma unroll
+                    for (int c = 0; c < kRowEdgeChunks; ++c) top = max(top, max(au[c], av[c]));
+                    if (top == 0xFFu) {
+#pragma unroll
+                        for (int c = 0; c < kRowEdgeChunks; ++c)
+                            bad = bad || ((c < nch ? gates[c] : 0u) != 0u && max(au[c], av[c]) == 0xFFu);
+                    }
+                    // visited qubits against their cores at the previous visit; the others against themselves
+                    const uint32_t f0 = (vm.x & p0) | (~vm.x & cur.x), f1 = (vm.y & p1) | (~vm.y & cur.y);
+                    const uint32_t f2 = (vm.z & p2) | (~vm.z & cur.z), f3 = (vm.w & p3) | (~vm.w & cur.w);
+                    if (f0 != cur.x) count4(f0, cur.x);
+                    if (f1 != cur.y) count4(f1, cur.y);
+                    if (f2 != cur.z) count4(f2, cur.z);
+                    if (f3 != cur.w) count4(f3, cur.w);
+                    if ((bytes_ff(cur.x & vm.x) | bytes_ff(cur.y & vm.y) | bytes_ff(cur.z & vm.z) | bytes_ff(cur.w & vm.w)) != 0)
+                        bad = bad || walk_lost(vm.x, p0, cur.x) || walk_lost(vm.y, p1, cur.y) || walk_lost(vm.z, p2, cur.z) ||
+                              walk_lost(vm.w, p3, cur.w);
+                    p0 = (vm.x & cur.x) | (~vm.x & p0);
+                    p1 = (vm.y & cur.y) | (~vm.y & p1);
+                    p2 = (vm.z & cur.z) | (~vm.z & p2);
+                    p3 = (vm.w & cur.w) | (~vm.w & p3);
+                    return;
                 }
                 if (row >= (ACTIVITY ? 1 : 2)) {  // movement is charged from row 2 on (events are counted from row 1 on); a dword of qubits that all stayed is skipped
                     if (c0 != p0) count4(p0, c0);
@@ -1258,11 +1341,11 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_pairs(V3Args p) {
             int g0 = w0;
             for (; g0 + AHEAD <= w1; g0 += AHEAD) {
 #pragma unroll
-                for (int k = 0; k < AHEAD; ++k) do_row(g0 + k, ring[k], gring[k], sring[k], ering[k], true);
+                for (int k = 0; k < AHEAD; ++k) do_row(g0 + k, ring[k], mring[WALK ? k : 0], gring[k], sring[k], ering[k], true);
             }
 #pragma unroll
             for (int k = 0; k < AHEAD - 1; ++k)
-                if (g0 + k < w1) do_row(g0 + k, ring[k], gring[k], sring[k], ering[k], false);
+                if (g0 + k < w1) do_row(g0 + k, ring[k], mring[WALK ? k : 0], gring[k], sring[k], ering[k], false);
         }
         __syncthreads();
         if constexpr (ACTIVITY) {
@@ -1278,6 +1361,9 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_pairs(V3Args p) {
         }
         double acc = apply_pair_counts<kV3Threads>(cnt, fold);
         acc = wave_sum(acc);
+        if constexpr (WALK) {
+            if (__builtin_amdgcn_ballot_w64(bad) != 0) acc = std::numeric_limits<double>::infinity();
+        }
         if (lane == 0) red[wave] = acc;
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -1288,6 +1374,17 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_pairs(V3Args p) {
         // the next item's counting cannot pass the barrier after it before thread 0 has read red[]; its
         // counter updates touch entries this pass has already zeroed or left at zero
     }
+}
+
+template <int AHEAD = kV3Ahead, bool ACTIVITY = false>
+__global__ __launch_bounds__(kV3Threads) void k_cost_v3_pairs(V3Args p) {
+    pairs_by_row<AHEAD, ACTIVITY, false>(p);
+}
+
+// Cost V2 / V4 with an fp64 table that is symmetric to rounding, by core-pair counts.
+template <int AHEAD>
+__global__ __launch_bounds__(kV3Threads) void k_cost_v2_pairs(V3Args p) {
+    pairs_by_row<AHEAD, false, true>(p);
 }
 
 // The same for rows of at most 512 bytes (grouped gate list, G rows per wave step as in k_cost_v3_groups): the
@@ -1968,9 +2065,10 @@ struct V2WalkArgs {
     const uint32_t* sched;
     const int32_t* sptr;
     const void* table;
-    double* out;
-    int64_t B;
-    int32_t T, Tp, ldq, C;
+    const int16_t* vprev;  // needed when a partition is split (rows_per_item < T)
+    double* partial;       // [chunk][B]
+    int64_t B, nitems;
+    int32_t T, Tp, ldq, C, rows_per_item;
 };
 
 template <bool V4, int AHEAD>
@@ -2001,20 +2099,13 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v2_walk(V2WalkArgs p) {
         entries_at_halves<E>(__builtin_amdgcn_perm(from, to, 0x07030602u), tbase, e2, e3);
         return ((uint32_t)e0 + e1) + ((uint32_t)e2 + e3);
     };
-    // non-zero iff some byte of y is 0xFF
-    auto any_ff = [](uint32_t y) -> uint32_t { return (~y - 0x01010101u) & y & 0x80808080u; };
-    // a visited byte (m) that is 0xFF in the row (c) but not in the last cores (l)
-    auto lost = [](uint32_t m, uint32_t l, uint32_t c) -> bool {
-        int n = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            n += (((m >> (8 * j)) & 0xFFu) != 0 && ((c >> (8 * j)) & 0xFFu) == 0xFFu && ((l >> (8 * j)) & 0xFFu) != 0xFFu) ? 1 : 0;
-        return n != 0;
-    };
     const uint32_t* sched_lane = p.sched + lane;
-    const int T = p.T;
 
-    for (int64_t b = (int64_t)blockIdx.x * kV3Waves + wave; b < p.B; b += (int64_t)gridDim.x * kV3Waves) {
+    for (int64_t it = (int64_t)blockIdx.x * kV3Waves + wave; it < p.nitems; it += (int64_t)gridDim.x * kV3Waves) {
+        const int chunk = (int)(it / p.B);
+        const int64_t b = it - (int64_t)chunk * p.B;
+        const int r0 = chunk * p.rows_per_item;
+        const int T = min(p.T, r0 + p.rows_per_item);  // the item's rows are r0 .. T - 1
         const uint8_t* base = p.A + (size_t)b * p.Tp * ldq;
         auto fetch_row = [&](int row) -> uint4 { return load_row16(base + (size_t)min(row, T - 1) * ldq + lane16); };
         auto fetch_mask = [&](int row) -> uint4 {  // lanes past the end of the row visit nothing
@@ -2022,19 +2113,21 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v2_walk(V2WalkArgs p) {
             return make_uint4(m.x & lane_mask, m.y & lane_mask, m.z & lane_mask, m.w & lane_mask);
         };
         auto fetch_gate = [&](int row, int c) -> uint32_t { return sched_lane[p.sptr[min(row, T - 1)] + c * kWave]; };
-        uint32_t l0 = ~0u, l1 = ~0u, l2 = ~0u, l3 = ~0u;
+        uint32_t st[4];
+        walk_state_at(base, p.vprev, r0, ldq, lane16, st);
+        uint32_t l0 = st[0], l1 = st[1], l2 = st[2], l3 = st[3];
         unsigned long long total = 0;
         bool bad = false;
         uint4 ring[AHEAD], mring[AHEAD];
         uint32_t gring[AHEAD][kRowEdgeChunks];
 #pragma unroll
         for (int k = 0; k < AHEAD; ++k) {
-            ring[k] = fetch_row(k);
-            mring[k] = fetch_mask(k);
+            ring[k] = fetch_row(r0 + k);
+            mring[k] = fetch_mask(r0 + k);
 #pragma unroll
-            for (int c = 0; c < kRowEdgeChunks; ++c) gring[k][c] = fetch_gate(k, c);
+            for (int c = 0; c < kRowEdgeChunks; ++c) gring[k][c] = fetch_gate(r0 + k, c);
         }
-        for (int g0 = 0; g0 < T; g0 += AHEAD) {
+        for (int g0 = r0; g0 < T; g0 += AHEAD) {
             uint32_t acc = 0;  // at most AHEAD * (16 + gates of a slice / 64 + 1) terms below 2^16 each
 #pragma unroll
             for (int k = 0; k < AHEAD; ++k) {
@@ -2066,8 +2159,9 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v2_walk(V2WalkArgs p) {
                 if (f1 != cur.y) acc += V4 ? four(cur.y, f1) : four(f1, cur.y);
                 if (f2 != cur.z) acc += V4 ? four(cur.z, f2) : four(f2, cur.z);
                 if (f3 != cur.w) acc += V4 ? four(cur.w, f3) : four(f3, cur.w);
-                if ((any_ff(cur.x & vm.x) | any_ff(cur.y & vm.y) | any_ff(cur.z & vm.z) | any_ff(cur.w & vm.w)) != 0)
-                    bad = bad || lost(vm.x, l0, cur.x) || lost(vm.y, l1, cur.y) || lost(vm.z, l2, cur.z) || lost(vm.w, l3, cur.w);
+                if ((bytes_ff(cur.x & vm.x) | bytes_ff(cur.y & vm.y) | bytes_ff(cur.z & vm.z) | bytes_ff(cur.w & vm.w)) != 0)
+                    bad = bad || walk_lost(vm.x, l0, cur.x) || walk_lost(vm.y, l1, cur.y) || walk_lost(vm.z, l2, cur.z) ||
+                          walk_lost(vm.w, l3, cur.w);
                 l0 = (vm.x & cur.x) | (~vm.x & l0);
                 l1 = (vm.y & cur.y) | (~vm.y & l1);
                 l2 = (vm.z & cur.z) | (~vm.z & l2);
@@ -2098,7 +2192,7 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v2_walk(V2WalkArgs p) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off, kWave);
         const bool any_bad = __builtin_amdgcn_ballot_w64(bad) != 0;
-        if (lane == 0) p.out[b] = any_bad ? std::numeric_limits<double>::infinity() : (double)total;
+        if (lane == 0) p.partial[it] = any_bad ? std::numeric_limits<double>::infinity() : (double)total;
     }
 }
 
@@ -2818,29 +2912,87 @@ extern "C" int qp_slice_cost_v2(const QpCircuit* circ, const QpDTable* dt, const
         HIP_TRY(hipGetLastError());
         return QP_OK;
     }
-    // Many partitions of a circuit that visits most of every row (over 128 qubits a slice, where reading whole rows
-    // beats gathering the visited bytes): the row walk.  16-bit tables only: its sums are integers.
-    if (flags != QP_V1 && dt->kind == QP_DT_U16 && ldq > 512 && ldq <= 1024 && B >= 1024 && circ->visit_mask &&
-        circ->visit_mask_ldq == ldq && circ->edges_sched && circ->sched_ptr && (int64_t)circ->nV >= (int64_t)128 * T) {
+    // A circuit that visits most of every row (over 128 qubits a slice, where reading whole rows beats gathering the
+    // visited bytes), enough rows to fill the GPU: the row walk.  16-bit tables are looked up (integer sums); fp64 tables
+    // that are symmetric to rounding are applied to core-pair counts; other fp64 tables stay with the visits.
+    const bool walkable = flags != QP_V1 && ldq > 512 && ldq <= 1024 && circ->visit_mask && circ->visit_mask_ldq == ldq &&
+                          circ->edges_sched && circ->sched_ptr && (int64_t)circ->nV >= (int64_t)128 * T &&
+                          (circ->visit_prev ? (int64_t)B * T >= 65536 : B >= 1024);
+    const int wcus = qp::device_cus();
+    if (walkable && dt->kind == QP_DT_U16) {
         V2WalkArgs w{};
         w.A = A;
         w.vmask = circ->visit_mask;
+        w.vprev = circ->visit_prev;
         w.sched = circ->edges_sched;
         w.sptr = circ->sched_ptr;
         w.table = dt->table;
-        w.out = out;
         w.B = B;
         w.T = T;
         w.Tp = Tp;
         w.ldq = ldq;
         w.C = dt->C;
+        // whole partitions when there are two or more per wave the GPU holds, else chunks of 64 slices or more
+        int32_t wchunks = 1;
+        if (circ->visit_prev)
+            wchunks = (int32_t)std::max<int64_t>(1, std::min<int64_t>(T / 64, ((int64_t)wcus * kV3Waves * 2 + B - 1) / B));
+        w.rows_per_item = (T + wchunks - 1) / wchunks;
+        wchunks = (T + w.rows_per_item - 1) / w.rows_per_item;
+        w.nitems = (int64_t)wchunks * B;
+        if (wchunks == 1) {
+            w.partial = out;
+        } else {
+            if (!workspace || workspace_bytes < (size_t)w.nitems * sizeof(double))
+                return qp::fail(QP_ENOSPC, "qp_slice_cost_v2: workspace needs %zu bytes", (size_t)w.nitems * sizeof(double));
+            w.partial = static_cast<double*>(workspace);
+        }
         void (*walk)(V2WalkArgs) = flags == QP_V4 ? k_cost_v2_walk<true, kV3Ahead> : k_cost_v2_walk<false, kV3Ahead>;
         const size_t lds = (size_t)256 * 256 * sizeof(uint16_t) + (size_t)kV3Waves * ldq;
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(walk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        const unsigned grid = (unsigned)std::min<int64_t>(qp::device_cus(), (B + kV3Waves - 1) / kV3Waves);
+        const unsigned grid = (unsigned)std::min<int64_t>(wcus, (w.nitems + kV3Waves - 1) / kV3Waves);
         walk<<<grid, kV3Threads, lds, stream>>>(w);
         HIP_TRY(hipGetLastError());
+        if (wchunks > 1) {
+            k_sum_chunks<<<(unsigned)((B + 255) / 256), 256, 0, stream>>>(w.partial, B, wchunks, out);
+            HIP_TRY(hipGetLastError());
+        }
         return QP_OK;
+    }
+    if (walkable && dt->kind == QP_DT_F64 && dt->symmetric && dt->C >= 2 && circ->visit_prev) {
+        // as the dense cost does it: whole workgroups take an item, about 8 items per workgroup
+        V3Args q{};
+        q.A = A;
+        q.edges_sched = circ->edges_sched;
+        q.sptr = circ->sched_ptr;
+        q.vmask = circ->visit_mask;
+        q.vprev = circ->visit_prev;
+        q.B = B;
+        q.T = T;
+        q.Tp = Tp;
+        q.ldq = ldq;
+        q.Q = circ->Q;
+        q.C = dt->C;
+        const int64_t want = ((int64_t)T * B + (int64_t)wcus * 8 - 1) / ((int64_t)wcus * 8);
+        q.rows_per_item = (int)std::min<int64_t>(T, std::max<int64_t>(4 * kV3Waves, (want + kV3Waves - 1) / kV3Waves * kV3Waves));
+        const int32_t pchunks = (T + q.rows_per_item - 1) / q.rows_per_item;
+        q.nitems = (int64_t)pchunks * B;
+        const size_t part_bytes = ((size_t)q.nitems * sizeof(double) + 255) & ~(size_t)255;
+        const size_t fold_bytes = (size_t)kPairSlots * sizeof(double);
+        const size_t pairs_lds = (size_t)kPairSlots * sizeof(uint32_t) + (size_t)kV3Waves * ldq + kV3Waves * sizeof(double);
+        if (workspace && workspace_bytes >= part_bytes + fold_bytes) {
+            q.partial = static_cast<double*>(workspace);
+            double* fold = reinterpret_cast<double*>(static_cast<uint8_t*>(workspace) + part_bytes);
+            k_sym_fold<<<kPairSlots / 256, 256, 0, stream>>>(static_cast<const double*>(dt->table), dt->C, fold);
+            HIP_TRY(hipGetLastError());
+            q.table = fold;
+            void (*pk)(V3Args) = k_cost_v2_pairs<kV3Ahead>;
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pairs_lds));
+            pk<<<(unsigned)std::min<int64_t>(wcus, q.nitems), kV3Threads, pairs_lds, stream>>>(q);
+            HIP_TRY(hipGetLastError());
+            k_sum_chunks<<<(unsigned)((B + 255) / 256), 256, 0, stream>>>(q.partial, B, pchunks, out);
+            HIP_TRY(hipGetLastError());
+            return QP_OK;
+        }
     }
     if (!circ->slice_visit_ptr || !circ->visits) return qp::fail(QP_EINVAL, "qp_slice_cost_v2: circuit visit tables missing");
     V2Args p{};

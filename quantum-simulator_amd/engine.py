@@ -128,6 +128,7 @@ class DeviceCircuit:
         # rows of 513 to 1024 bytes: which qubits every slice visits, for the row walk of the gate-ordered cost
         # (visit_mask=False leaves it out: the cost is then always taken visit by visit)
         self._vmask = _to_dev(ir.visit_mask(self.ldq), self.device) if visit_mask and 512 < self.ldq <= 1024 and ir.T else None
+        self._vprev = _to_dev(ir.visit_prev(self.ldq), self.device) if self._vmask is not None and ir.T <= 32767 else None
         self.c = QpCircuit(ir.Q, ir.T, ir.nE, ir.nV, most, self.ldq if grouped is not None else 0,
                            self._sep.data_ptr(), self._edges.data_ptr(),
                            self._la.data_ptr(), self._svp.data_ptr(), self._visits.data_ptr(),
@@ -135,7 +136,8 @@ class DeviceCircuit:
                            self._gsched.data_ptr() if grouped is not None else None,
                            self._gptr.data_ptr() if grouped is not None else None,
                            self._vmask.data_ptr() if self._vmask is not None else None,
-                           self.ldq if self._vmask is not None else 0, 0)
+                           self.ldq if self._vmask is not None else 0, 0,
+                           self._vprev.data_ptr() if self._vprev is not None else None)
 
     @property
     def csr_bytes(self):

@@ -311,6 +311,12 @@ class CircuitIR:
             vm[self.visit_records["t"], self.visit_records["q"]] = 0xFF
         return vm
 
+    def visit_prev(self, ldq: int) -> np.ndarray:
+        """int16 [T, ldq]: the last slice before t that visits the qubit (visit_mask), -1 if none."""
+        seen = np.where(self.visit_mask(ldq) != 0, np.arange(self.T, dtype=np.int32)[:, None], -1)
+        run = np.maximum.accumulate(seen, axis=0)
+        return np.vstack([np.full((1, int(ldq)), -1, np.int32), run[:-1]]).astype(np.int16)
+
     def grouped_edges(self, ldq: int):
         """(group_ptr, words) for partitions with rows of ``ldq`` <= 512 bytes, or None when the rows are longer:
         the counted gates of every ``64 // (ldq // 16)`` consecutive slices together, endpoints as byte offsets

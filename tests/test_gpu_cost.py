@@ -449,12 +449,15 @@ def test_cost_v2_random(gpu, Q, T, C, B, integer):
         assert _close(got[0], want, integer)
 
 
-@pytest.mark.parametrize("Q,T,C,B,drop", [(1024, 37, 255, 1024, 0.05), (1000, 21, 16, 1100, 0.3), (600, 50, 100, 1030, 0.0),
-                                           (513, 9, 2, 1024, 0.2), (777, 130, 64, 1024, 0.1)])
-def test_cost_v2_row_walk(gpu, Q, T, C, B, drop):
-    """Large batches on a circuit that visits most qubits in most slices are walked row by row (16-bit tables): equal to
-    the visit-by-visit kernel on every partition and to the oracle on a sample, absent qubits and the errors they cause
-    included."""
+@pytest.mark.parametrize("Q,T,C,B,drop,integer", [
+    (1024, 37, 255, 1024, 0.05, True), (1000, 21, 16, 1100, 0.3, True), (600, 50, 100, 1030, 0.0, True),
+    (513, 9, 2, 1024, 0.2, True), (777, 130, 64, 1024, 0.1, True), (1024, 260, 200, 260, 0.1, True),
+    (1024, 37, 255, 2000, 0.05, False), (1000, 300, 16, 230, 0.3, False), (600, 129, 100, 520, 0.0, False),
+    (513, 70, 2, 1024, 0.2, False)])
+def test_cost_v2_row_walk(gpu, Q, T, C, B, drop, integer):
+    """Batches on a circuit that visits most qubits in most slices are walked row by row (16-bit tables looked up,
+    symmetric fp64 tables through core-pair counts; few partitions in chunks of slices): equal to the visit-by-visit
+    kernel on every partition and to the oracle on a sample, absent qubits and the errors they cause included."""
     from quantum_simulator_amd import layered_gate_arrays
     from quantum_simulator_amd.timeslices import CircuitIR
     torch, engine, eng, dev = gpu
@@ -467,12 +470,13 @@ def test_cost_v2_row_walk(gpu, Q, T, C, B, drop):
     ev = list(range(1, C)) + [int(x) for x in rng.integers(0, C, size=C)]
     ok = [k for k in range(len(eu)) if eu[k] != ev[k]]
     eu, ev = [eu[k] for k in ok], [ev[k] for k in ok]
-    D = engine.apsp(C, eu, ev, rng.integers(1, 9, size=len(eu)).astype(float))
+    D = engine.apsp(C, eu, ev, rng.integers(1, 9, size=len(eu)).astype(float) if integer else rng.uniform(1, 3, size=len(eu)))
     H = engine.hops(C, eu, ev)
     walk, byvisit = engine.DeviceCircuit(ir, dev), engine.DeviceCircuit(ir, dev, visit_mask=False)
-    assert walk.c.visit_mask and not byvisit.c.visit_mask
+    assert walk.c.visit_mask and walk.c.visit_prev and not byvisit.c.visit_mask
     dt, ht = engine.DistanceTable(D, dev), engine.DistanceTable(H, dev)
-    assert dt.kind == engine.QP_DT_U16
+    assert (dt.kind == engine.QP_DT_U16) == integer and ht.kind == engine.QP_DT_U16
+    assert integer or dt.packed.symmetric
     Tp = ir.T + (Q % 2)
     A = rng.integers(0, C, size=(B, Tp, walk.ldq), dtype=np.uint8)
     A[:, :, Q:] = rng.integers(0, 256, size=(B, Tp, walk.ldq - Q), dtype=np.uint8)
@@ -498,7 +502,13 @@ def test_cost_v2_row_walk(gpu, Q, T, C, B, drop):
     for variant, fn, tab, tabl in ((engine.QP_V2, O.cost_v2, dt, Dl), (engine.QP_V4, O.cost_v4, ht, Hl)):
         got = eng.cost_v2(walk, tab, Ad, variant).cpu().numpy()
         ref = eng.cost_v2(byvisit, tab, Ad, variant).cpu().numpy()
-        assert got.tobytes() == ref.tobytes(), (variant, np.flatnonzero(got != ref)[:8])
+        exact = integer or variant == engine.QP_V4
+        if exact:
+            assert got.tobytes() == ref.tobytes(), (variant, np.flatnonzero(got != ref)[:8])
+        else:  # pair counts times the symmetrised table against a sum in visit order
+            assert (np.isinf(got) == np.isinf(ref)).all()
+            fin = np.isfinite(ref)
+            assert np.allclose(got[fin], ref[fin], rtol=1e-12, atol=0)
         assert np.isinf(got[60:80]).any() and np.isfinite(got[:60]).all()
         for b in (0, 41, 60, 65, 70, 75, 79, B - 1):
             rows = [[None if c == 0xFF else int(c) for c in r[:Q]] for r in A[b, :ir.T]]
@@ -506,7 +516,7 @@ def test_cost_v2_row_walk(gpu, Q, T, C, B, drop):
                 want = float(fn(ir.slices, ir.gate_q, ir.gate_mr, rows, tabl))
             except O.CostError:
                 want = float("inf")
-            assert got[b] == want, (variant, b, got[b], want)
+            assert _close(got[b], want, exact, nterms=ir.nV + ir.nE), (variant, b, got[b], want)
 
 
 def test_cost_v3_rejects_bad_arguments(gpu):
