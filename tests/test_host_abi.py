@@ -150,6 +150,20 @@ def test_ir_tables(name):
             for q in gc.gate_q[g]:
                 last[q] = t
     assert k == ir.nV
+    # the same per (slice, qubit), as the row walk of the gate-ordered cost reads it
+    ldq = (gc.Q + 15) // 16 * 16
+    vm, vp = ir.visit_mask(ldq), ir.visit_prev(ldq)
+    assert vm.shape == vp.shape == (ir.T, ldq) and vm.dtype == np.uint8 and vp.dtype == np.int16
+    seen = np.zeros((ir.T, ldq), bool)
+    seen[ir.visit_records["t"], ir.visit_records["q"]] = True
+    assert ((vm == 0xFF) == seen).all() and ((vm == 0) == ~seen).all()
+    assert (vp[ir.visit_records["t"], ir.visit_records["q"]] == ir.visit_records["prev_t"]).all()
+    for q in range(ldq):
+        last = -1
+        for t in range(ir.T):
+            assert vp[t, q] == last
+            if seen[t, q]:
+                last = t
 
 
 def test_qasm_reader_matches_fixture_tables():

@@ -124,7 +124,17 @@ def main():
         return [pick(2, 80), pick(81, 512), pick(513, 1024), pick(1025, 1600)][pick(0, 3)]
 
     def draw():
-        kind = pick(0, 11)
+        kind = pick(0, 12)
+        if os.environ.get("QP_FUZZ_KIND"):  # one kind of case only
+            kind = int(os.environ["QP_FUZZ_KIND"])
+        if kind == 12:  # gate-ordered cost as a row walk: whole partitions or chunks of slices, looked up or pair-counted
+            if pick(0, 1):
+                B, T = pick(1024, 1400), pick(1, 40)
+            else:
+                B = pick(270, 600)
+                T = pick(65536 // B - 20, min(250, 65536 // B + 120))
+            return "cost_v2_row_walk", TC.test_cost_v2_row_walk, (gpu, pick(513, 1024), T, pick(2, 255), B, float(rng.choice([0.0, 0.1, 0.3])),
+                                                                  bool(pick(0, 1)))
         if kind == 11:  # rows of at most 512 bytes through the grouped gate list: every table form, one or several items
             Q = pick(2, 512)
             ldq = (Q + 15) // 16 * 16
