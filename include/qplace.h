@@ -309,7 +309,7 @@ int qp_slice_cost_v3_static(const QpCircuit* circ, const QpDTable* dt, const uin
  *   QP_V4  Qubo_placer.py:177-207 (pass the hop-count table; movement is looked up as [cur][last])
  * Where the reference would raise (absent qubit of a counted gate in V2/V4; a qubit placed at its
  * previous visit and absent now) out[b] = +inf, which is what main.py:99-102 records for the repeat.
- * With visit_mask (and visit_prev) in the circuit, V2 / V4 batches of 65536 rows or more on a circuit that visits
+ * With visit_mask (and visit_prev) in the circuit, batches of 65536 rows or more on a circuit that visits
  * over 128 qubits per slice are read row by row: a QP_DT_U16 table gives the same integers; a QP_DT_F64 table with
  * dt->symmetric set is applied as (D[a][b] + D[b][a]) / 2 to counts of core pairs (as in qp_slice_cost_v3; within
  * the table's asymmetry of the visit-by-visit sums).  Sums are formed in a fixed order either way. */

@@ -166,6 +166,8 @@ struct V3Args {
     unsigned long long* activity;  // k_cost_v3_pairs<., true>: per-core event counts [B][C] instead of a cost
     const uint8_t* vmask;          // k_cost_v2_pairs: [T][ldq] 0xFF where a slice visits the qubit
     const int16_t* vprev;          // k_cost_v2_pairs: [T][ldq] last slice before t that visits the qubit, -1 if none
+    int32_t gate_errors;           // k_cost_v2_pairs: non-zero = a counted gate with an operand on no core is an error
+                                   // (V2, V4); zero = it adds nothing (V1)
     int32_t parts_per_item;  // k_cost_v3_groups: consecutive partitions a wave takes as one stream of steps (> 1 only
     int64_t nbgroups;        // when an item is a whole partition), and how many such groups of partitions there are
     // grid metric (kTabGrid): byte-replicated masks of the x and y fields of a core id, the shift that
@@ -1158,7 +1160,7 @@ __device__ inline void walk_state_at(const uint8_t* base, const int16_t* vprev, 
     }
 }
 
-// WALK: the gate-ordered cost (V2 / V4, which differ only in the table the caller passes once it is symmetrised)
+// WALK: the gate-ordered cost (V1 / V2 / V4; V2 and V4 differ only in the table the caller passes once it is symmetrised)
 // instead of the dense one: movement of the qubits a slice visits against their cores at their previous visit (see
 // k_cost_v2_walk), from the first row on; a wave's run starts from the state walk_state_at gathers.
 template <int AHEAD, bool ACTIVITY, bool WALK>
@@ -1297,14 +1299,14 @@ __device__ __forceinline__ void pairs_by_row(const V3Args& p) {
                     const uint32_t g = sched_lane[s0 + c * kWave];
                     const uint32_t u = strip[g & 0xFFFFu], v = strip[g >> 16];
                     count_gates2(u, v);  // the upper halves are the pair (0, 0): a diagonal slot
-                    if constexpr (WALK) bad = bad || (g != 0u && max(u, v) == 0xFFu);
+                    if constexpr (WALK) bad = bad || (p.gate_errors && g != 0u && max(u, v) == 0xFFu);
                 }
                 if constexpr (WALK) {
                     // a counted gate (padding words are zero) with an operand on no core
                     uint32_t top = 0;
 #pragma unroll
                     for (int c = 0; c < kRowEdgeChunks; ++c) top = max(top, max(au[c], av[c]));
-                    if (top == 0xFFu) {
+                    if (top == 0xFFu && p.gate_errors) {
 #pragma unroll
                         for (int c = 0; c < kRowEdgeChunks; ++c)
                             bad = bad || ((c < nch ? gates[c] : 0u) != 0u && max(au[c], av[c]) == 0xFFu);
@@ -1381,7 +1383,7 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_pairs(V3Args p) {
     pairs_by_row<AHEAD, ACTIVITY, false>(p);
 }
 
-// Cost V2 / V4 with an fp64 table that is symmetric to rounding, by core-pair counts.
+// Cost V1 / V2 / V4 with an fp64 table that is symmetric to rounding, by core-pair counts.
 template <int AHEAD>
 __global__ __launch_bounds__(kV3Threads) void k_cost_v2_pairs(V3Args p) {
     pairs_by_row<AHEAD, false, true>(p);
@@ -2047,7 +2049,7 @@ __global__ __launch_bounds__(THREADS) void k_cost_v2(V2Args p) {
     }
 }
 
-// Cost V2 / V4 as a row walk, for circuits that visit most qubits in most slices (rows of 513 to 1024 bytes, 16-bit
+// Cost V1 / V2 / V4 as a row walk, for circuits that visit most qubits in most slices (rows of 513 to 1024 bytes, 16-bit
 // table).  One wave owns a partition and reads its rows once, 16 bytes per lane; the core every qubit had at its last
 // visit stays in four registers per lane (0xFF = not visited yet, or on no core then).  vmask holds, per slice, 0xFF in
 // the bytes of the qubits the slice visits, so
@@ -2069,6 +2071,7 @@ struct V2WalkArgs {
     double* partial;       // [chunk][B]
     int64_t B, nitems;
     int32_t T, Tp, ldq, C, rows_per_item;
+    int32_t gate_errors;  // non-zero: a counted gate with an operand on no core is an error (V2, V4); zero: it adds nothing (V1)
 };
 
 template <bool V4, int AHEAD>
@@ -2170,7 +2173,7 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v2_walk(V2WalkArgs p) {
                 uint32_t top = 0;
 #pragma unroll
                 for (int c = 0; c < kRowEdgeChunks; ++c) top = max(top, max(au[c], av[c]));
-                if (top == 0xFFu) {
+                if (top == 0xFFu && p.gate_errors) {
 #pragma unroll
                     for (int c = 0; c < kRowEdgeChunks; ++c) bad = bad || (gates[c] != 0u && max(au[c], av[c]) == 0xFFu);
                 }
@@ -2183,7 +2186,7 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v2_walk(V2WalkArgs p) {
                 for (int c = kRowEdgeChunks; c < nch; ++c) {
                     const uint32_t g = sched_lane[s0 + c * kWave];
                     const uint32_t cu = strip[g & 0xFFFFu], cv = strip[g >> 16];
-                    bad = bad || (g != 0u && max(cu, cv) == 0xFFu);
+                    bad = bad || (p.gate_errors && g != 0u && max(cu, cv) == 0xFFu);
                     acc += tab[(cu << 8) | cv];
                 }
             }
@@ -2915,7 +2918,7 @@ extern "C" int qp_slice_cost_v2(const QpCircuit* circ, const QpDTable* dt, const
     // A circuit that visits most of every row (over 128 qubits a slice, where reading whole rows beats gathering the
     // visited bytes), enough rows to fill the GPU: the row walk.  16-bit tables are looked up (integer sums); fp64 tables
     // that are symmetric to rounding are applied to core-pair counts; other fp64 tables stay with the visits.
-    const bool walkable = flags != QP_V1 && ldq > 512 && ldq <= 1024 && circ->visit_mask && circ->visit_mask_ldq == ldq &&
+    const bool walkable = ldq > 512 && ldq <= 1024 && circ->visit_mask && circ->visit_mask_ldq == ldq &&
                           circ->edges_sched && circ->sched_ptr && (int64_t)circ->nV >= (int64_t)128 * T &&
                           (circ->visit_prev ? (int64_t)B * T >= 65536 : B >= 1024);
     const int wcus = qp::device_cus();
@@ -2932,6 +2935,7 @@ extern "C" int qp_slice_cost_v2(const QpCircuit* circ, const QpDTable* dt, const
         w.Tp = Tp;
         w.ldq = ldq;
         w.C = dt->C;
+        w.gate_errors = flags != QP_V1;
         // whole partitions when there are two or more per wave the GPU holds, else chunks of 64 slices or more
         int32_t wchunks = 1;
         if (circ->visit_prev)
@@ -2972,6 +2976,7 @@ extern "C" int qp_slice_cost_v2(const QpCircuit* circ, const QpDTable* dt, const
         q.ldq = ldq;
         q.Q = circ->Q;
         q.C = dt->C;
+        q.gate_errors = flags != QP_V1;
         const int64_t want = ((int64_t)T * B + (int64_t)wcus * 8 - 1) / ((int64_t)wcus * 8);
         q.rows_per_item = (int)std::min<int64_t>(T, std::max<int64_t>(4 * kV3Waves, (want + kV3Waves - 1) / kV3Waves * kV3Waves));
         const int32_t pchunks = (T + q.rows_per_item - 1) / q.rows_per_item;
