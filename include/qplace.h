@@ -83,7 +83,7 @@ typedef struct QpCircuit {
                                        into those rows, padded like edges_sched); the dense cost kernels for short
                                        rows read this list when the partitions' row pitch equals group_ldq */
     const int32_t* group_ptr;       /* [ceil(T / qp_group_rows(group_ldq)) + 1] start of every group (required with it) */
-    const uint8_t* visit_mask;      /* optional, rows of 513 to 1024 bytes: [T][visit_mask_ldq] bytes, 0xFF where the
+    const uint8_t* visit_mask;      /* optional, rows of up to 1024 bytes: [T][visit_mask_ldq] bytes, 0xFF where the
                                        qubit is an operand of some command of the slice (a visit of the gate-ordered
                                        walk), 0 elsewhere and in the padding; with it and edges_sched, large batches
                                        of the gate-ordered cost are walked row by row instead of visit by visit */
@@ -309,8 +309,8 @@ int qp_slice_cost_v3_static(const QpCircuit* circ, const QpDTable* dt, const uin
  *   QP_V4  Qubo_placer.py:177-207 (pass the hop-count table; movement is looked up as [cur][last])
  * Where the reference would raise (absent qubit of a counted gate in V2/V4; a qubit placed at its
  * previous visit and absent now) out[b] = +inf, which is what main.py:99-102 records for the repeat.
- * With visit_mask (and visit_prev) in the circuit, batches of 65536 rows or more on a circuit that visits
- * over 128 qubits per slice are read row by row: a QP_DT_U16 table gives the same integers; a QP_DT_F64 table with
+ * With visit_mask (and visit_prev) in the circuit, batches of 64 MB or more on a circuit that visits an eighth
+ * or more of every row (rows of up to 1024 bytes) are read row by row: a QP_DT_U16 table gives the same integers; a QP_DT_F64 table with
  * dt->symmetric set is applied as (D[a][b] + D[b][a]) / 2 to counts of core pairs (as in qp_slice_cost_v3; within
  * the table's asymmetry of the visit-by-visit sums).  Sums are formed in a fixed order either way. */
 #define QP_V2 0

@@ -2072,6 +2072,12 @@ struct V2WalkArgs {
     int64_t B, nitems;
     int32_t T, Tp, ldq, C, rows_per_item;
     int32_t gate_errors;  // non-zero: a counted gate with an operand on no core is an error (V2, V4); zero: it adds nothing (V1)
+    // k_cost_v2_walk_parts: the gate records (first dword of each = first operand | second << 16) and where every
+    // slice's start; 16-byte pieces per row, partitions per wave step, groups of that many partitions
+    const QpEdge* edges;
+    const int32_t* sep;
+    int32_t nE, lpr, G;
+    int64_t ngroups;
 };
 
 template <bool V4, int AHEAD>
@@ -2196,6 +2202,179 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v2_walk(V2WalkArgs p) {
         for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off, kWave);
         const bool any_bad = __builtin_amdgcn_ballot_w64(bad) != 0;
         if (lane == 0) p.partial[it] = any_bad ? std::numeric_limits<double>::infinity() : (double)total;
+    }
+}
+
+// The same walk for rows of at most 512 bytes.  A wave step is row t of G = 64 / (ldq / 16) consecutive partitions (not G
+// rows of one partition: the last cores then stay in the registers of the lane that owns the (partition, 16-byte piece),
+// with no scan over rows).  The strip holds the G rows side by side (lane * 16 is both where a lane parks its piece and
+// partition * ldq + piece * 16); slice t's gates are the same for all G partitions, so lane (partition g, slot k) takes
+// gates k, k + ldq / 16, ... of the slice against its own partition's row: every gate instruction serves 64 (gate,
+// partition) pairs.  Gates come from the edge records (slice order, no padding), the first kWalkGateChunks chunks of a
+// slice loaded together with the row.  Tables: 16-bit at pitch 256 (row and column 255 zero); fp64 of up to 64 cores
+// at pitch 256 followed by a zero entry that indices of absent sources are clamped onto.
+constexpr int kWalkGateChunks = 6;
+constexpr int kWalkPartsLds = 1024 + 768;  // per wave: the strip, then 64 sums and 64 error flags
+
+template <int KIND, bool V4, int AHEAD>
+__global__ __launch_bounds__(kV3Threads) void k_cost_v2_walk_parts(V2WalkArgs p) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    using E = typename Tab<KIND>::elem;
+    using Acc = typename Tab<KIND>::acc;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int nrows = KIND == QP_DT_U16 ? 256 : p.C;   // table rows staged; then one zero entry (fp64)
+    const uint32_t cap = (uint32_t)nrows << 8;          // index of the zero entry
+    {
+        const E* src = static_cast<const E*>(p.table);
+        E* dst = reinterpret_cast<E*>(smem);
+        for (int k = threadIdx.x; k < nrows * 256 + 2; k += blockDim.x) {
+            const int r = k >> 8, c = k & 255;
+            dst[k] = (r < p.C && c < p.C) ? src[r * p.C + c] : E(0);
+        }
+        __syncthreads();
+    }
+    const E* tab = reinterpret_cast<const E*>(smem);
+    const size_t tab_bytes = (((size_t)nrows * 256 + 2) * sizeof(E) + 15) & ~(size_t)15;
+    const int ldq = p.ldq, lpr = p.lpr, G = p.G;
+    uint8_t* strip = smem + tab_bytes + (size_t)wave * kWalkPartsLds;
+    const bool lane_on = lane < G * lpr;
+    const int g = lane_on ? lane / lpr : 0, piece = lane_on ? lane - g * lpr : 0;
+    const uint32_t lane_mask = lane_on ? ~0u : 0u;
+    const uint32_t goff = (uint32_t)(g * ldq);
+    auto at = [&](uint32_t from, uint32_t to) -> Acc {
+        const uint32_t idx = (from << 8) | to;
+        if constexpr (KIND == QP_DT_U16) return tab[idx];
+        else return tab[min(idx, cap)];
+    };
+    const uint32_t tbase = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_u8*)smem);
+    // four (from, to) pairs of a dword: from << 8 | to in 16-bit halves; fp64: both halves clamped onto the zero entry
+    auto four = [&](uint32_t from, uint32_t to) -> Acc {
+        uint32_t k01 = __builtin_amdgcn_perm(from, to, 0x05010400u), k23 = __builtin_amdgcn_perm(from, to, 0x07030602u);
+        if constexpr (KIND != QP_DT_U16) {
+            typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+            const u16x2 lim = {(unsigned short)cap, (unsigned short)cap};
+            k01 = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, k01), lim));
+            k23 = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, k23), lim));
+        }
+        E e0, e1, e2, e3;
+        entries_at_halves<E>(k01, tbase, e0, e1);
+        entries_at_halves<E>(k23, tbase, e2, e3);
+        return ((Acc)e0 + (Acc)e1) + ((Acc)e2 + (Acc)e3);
+    };
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(p.edges);  // records of 8 bytes: the pair is dword 0
+    const int last_edge = max(p.nE - 1, 0);
+
+    for (int64_t it = (int64_t)blockIdx.x * kV3Waves + wave; it < p.nitems; it += (int64_t)gridDim.x * kV3Waves) {
+        const int chunk = (int)(it / p.ngroups);
+        const int64_t b0 = (it - (int64_t)chunk * p.ngroups) * G;
+        const int64_t b = min(b0 + g, p.B - 1);  // a group that runs past B repeats the last partition and drops the copies
+        const int r0 = chunk * p.rows_per_item;
+        const int T = min(p.T, r0 + p.rows_per_item);
+        const uint8_t* part = p.A + (size_t)b * p.Tp * ldq;
+        const uint8_t* base = part + piece * 16;
+        auto fetch_row = [&](int row) -> uint4 { return load_row16(base + (size_t)min(row, T - 1) * ldq); };
+        auto fetch_mask = [&](int row) -> uint4 {
+            const uint4 m = *reinterpret_cast<const uint4*>(p.vmask + (size_t)min(row, T - 1) * ldq + piece * 16);
+            return make_uint4(m.x & lane_mask, m.y & lane_mask, m.z & lane_mask, m.w & lane_mask);
+        };
+        // gate `piece + c * lpr` of the slice, or a later slice's (the consumer checks the count)
+        auto fetch_gate = [&](int row, int c) -> uint32_t {
+            return words[2 * (size_t)min(p.sep[min(row, T - 1)] + c * lpr + piece, last_edge)];
+        };
+        uint32_t st[4];
+        walk_state_at(part, p.vprev, r0, ldq, piece * 16, st);
+        uint32_t l0 = st[0], l1 = st[1], l2 = st[2], l3 = st[3];
+        typename std::conditional<KIND == QP_DT_U16, unsigned long long, double>::type total = 0;
+        bool bad = false;
+        uint4 ring[AHEAD], mring[AHEAD];
+        uint32_t gring[AHEAD][kWalkGateChunks];
+#pragma unroll
+        for (int k = 0; k < AHEAD; ++k) {
+            ring[k] = fetch_row(r0 + k);
+            mring[k] = fetch_mask(r0 + k);
+#pragma unroll
+            for (int c = 0; c < kWalkGateChunks; ++c) gring[k][c] = fetch_gate(r0 + k, c);
+        }
+        for (int g0 = r0; g0 < T; g0 += AHEAD) {
+#pragma unroll
+            for (int k = 0; k < AHEAD; ++k) {
+                const int row = g0 + k;
+                if (row >= T) break;
+                const uint4 cur = ring[k], vm = mring[k];
+                uint32_t gates[kWalkGateChunks];
+#pragma unroll
+                for (int c = 0; c < kWalkGateChunks; ++c) gates[c] = gring[k][c];
+                ring[k] = fetch_row(row + AHEAD);
+                mring[k] = fetch_mask(row + AHEAD);
+#pragma unroll
+                for (int c = 0; c < kWalkGateChunks; ++c) gring[k][c] = fetch_gate(row + AHEAD, c);
+
+                if (lane_on) *reinterpret_cast<uint4*>(strip + lane * 16) = cur;
+                const int e0 = p.sep[row];
+                const int slice_gates = p.sep[row + 1] - e0;
+                const int mine = slice_gates - piece;  // gates c * lpr < mine are this lane's
+                uint32_t au[kWalkGateChunks], av[kWalkGateChunks];
+#pragma unroll
+                for (int c = 0; c < kWalkGateChunks; ++c) {
+                    if (!(lane_on && c * lpr < mine)) gates[c] = 0u;  // (qubit 0, qubit 0): one core twice, distance zero
+                    au[c] = av[c] = 0u;
+                    if (c * lpr < slice_gates) {  // the same for the whole wave
+                        au[c] = strip[goff + (gates[c] & 0xFFFFu)];
+                        av[c] = strip[goff + (gates[c] >> 16)];
+                    }
+                }
+                Acc acc = 0;
+                const uint32_t f0 = (vm.x & l0) | (~vm.x & cur.x), f1 = (vm.y & l1) | (~vm.y & cur.y);
+                const uint32_t f2 = (vm.z & l2) | (~vm.z & cur.z), f3 = (vm.w & l3) | (~vm.w & cur.w);
+                if (f0 != cur.x) acc += V4 ? four(cur.x, f0) : four(f0, cur.x);
+                if (f1 != cur.y) acc += V4 ? four(cur.y, f1) : four(f1, cur.y);
+                if (f2 != cur.z) acc += V4 ? four(cur.z, f2) : four(f2, cur.z);
+                if (f3 != cur.w) acc += V4 ? four(cur.w, f3) : four(f3, cur.w);
+                if ((bytes_ff(cur.x & vm.x) | bytes_ff(cur.y & vm.y) | bytes_ff(cur.z & vm.z) | bytes_ff(cur.w & vm.w)) != 0)
+                    bad = bad || walk_lost(vm.x, l0, cur.x) || walk_lost(vm.y, l1, cur.y) || walk_lost(vm.z, l2, cur.z) ||
+                          walk_lost(vm.w, l3, cur.w);
+                l0 = (vm.x & cur.x) | (~vm.x & l0);
+                l1 = (vm.y & cur.y) | (~vm.y & l1);
+                l2 = (vm.z & cur.z) | (~vm.z & l2);
+                l3 = (vm.w & cur.w) | (~vm.w & l3);
+                uint32_t top = 0, differ = 0;
+#pragma unroll
+                for (int c = 0; c < kWalkGateChunks; ++c) {
+                    top = max(top, max(au[c], av[c]));
+                    differ |= au[c] ^ av[c];
+                }
+                if (top == 0xFFu && p.gate_errors) {
+#pragma unroll
+                    for (int c = 0; c < kWalkGateChunks; ++c) bad = bad || (gates[c] != 0u && max(au[c], av[c]) == 0xFFu);
+                }
+                if (differ != 0) {
+#pragma unroll
+                    for (int c = 0; c < kWalkGateChunks; ++c) acc += at(au[c], av[c]);
+                }
+                for (int c = kWalkGateChunks; c * lpr < mine && lane_on; ++c) {
+                    const uint32_t w = words[2 * (size_t)(e0 + c * lpr + piece)];
+                    const uint32_t cu = strip[goff + (w & 0xFFFFu)], cv = strip[goff + (w >> 16)];
+                    bad = bad || (p.gate_errors && max(cu, cv) == 0xFFu);
+                    acc += at(cu, cv);
+                }
+                total += acc;  // 16-bit table: a lane adds 16 + gates / lpr terms below 2^16 per row into 32 bits here
+            }
+        }
+        // per partition: the sums and error flags of its lpr lanes, through LDS (a wave's LDS operations complete in order)
+        volatile double* sums = reinterpret_cast<volatile double*>(strip + 1024);
+        volatile uint32_t* flags = reinterpret_cast<volatile uint32_t*>(strip + 1024 + 512);
+        sums[lane] = (double)total;
+        flags[lane] = bad ? 1u : 0u;
+        if (lane_on && piece == 0 && b0 + g < p.B) {
+            double s = 0.0;
+            uint32_t any = 0;
+            for (int j = 0; j < lpr; ++j) {
+                s += sums[lane + j];
+                any |= flags[lane + j];
+            }
+            p.partial[(size_t)chunk * p.B + b] = any ? std::numeric_limits<double>::infinity() : s;
+        }
     }
 }
 
@@ -2922,6 +3101,55 @@ extern "C" int qp_slice_cost_v2(const QpCircuit* circ, const QpDTable* dt, const
                           circ->edges_sched && circ->sched_ptr && (int64_t)circ->nV >= (int64_t)128 * T &&
                           (circ->visit_prev ? (int64_t)B * T >= 65536 : B >= 1024);
     const int wcus = qp::device_cus();
+    // rows of at most 512 bytes: the same walk with G partitions per wave step
+    const int32_t wlpr = ldq / 16, wG = wlpr > 0 && wlpr <= 32 ? kWave / wlpr : 0;
+    if (wG >= 2 && circ->visit_mask && circ->visit_mask_ldq == ldq && circ->visit_prev && circ->edges && circ->slice_edge_ptr &&
+        circ->nE > 0 && (int64_t)circ->nV * 8 >= (int64_t)T * ldq && B >= wG && (int64_t)B * T * ldq >= ((int64_t)1 << 26) &&
+        (dt->kind == QP_DT_U16 || dt->C <= 64)) {
+        V2WalkArgs w{};
+        w.A = A;
+        w.vmask = circ->visit_mask;
+        w.vprev = circ->visit_prev;
+        w.edges = circ->edges;
+        w.sep = circ->slice_edge_ptr;
+        w.nE = circ->nE;
+        w.table = dt->table;
+        w.B = B;
+        w.T = T;
+        w.Tp = Tp;
+        w.ldq = ldq;
+        w.C = dt->C;
+        w.lpr = wlpr;
+        w.G = wG;
+        w.ngroups = (B + wG - 1) / wG;
+        w.gate_errors = flags != QP_V1;
+        int32_t wchunks = (int32_t)std::max<int64_t>(1, std::min<int64_t>(T / 64, ((int64_t)wcus * kV3Waves * 2 + w.ngroups - 1) / w.ngroups));
+        w.rows_per_item = (T + wchunks - 1) / wchunks;
+        wchunks = (T + w.rows_per_item - 1) / w.rows_per_item;
+        w.nitems = (int64_t)wchunks * w.ngroups;
+        if (wchunks == 1) {
+            w.partial = out;
+        } else {
+            if (!workspace || workspace_bytes < (size_t)wchunks * B * sizeof(double))
+                return qp::fail(QP_ENOSPC, "qp_slice_cost_v2: workspace needs %zu bytes", (size_t)wchunks * B * sizeof(double));
+            w.partial = static_cast<double*>(workspace);
+        }
+        const bool v4 = flags == QP_V4;
+        void (*walk)(V2WalkArgs) =
+            dt->kind == QP_DT_U16 ? (v4 ? k_cost_v2_walk_parts<QP_DT_U16, true, 3> : k_cost_v2_walk_parts<QP_DT_U16, false, 3>)
+                                  : (v4 ? k_cost_v2_walk_parts<QP_DT_F64, true, 3> : k_cost_v2_walk_parts<QP_DT_F64, false, 3>);
+        const size_t entries = (size_t)(dt->kind == QP_DT_U16 ? 256 : dt->C) * 256 + 2;
+        const size_t lds = ((entries * (dt->kind == QP_DT_U16 ? 2 : 8) + 15) & ~(size_t)15) + (size_t)kV3Waves * kWalkPartsLds;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(walk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const unsigned grid = (unsigned)std::min<int64_t>(wcus, (w.nitems + kV3Waves - 1) / kV3Waves);
+        walk<<<grid, kV3Threads, lds, stream>>>(w);
+        HIP_TRY(hipGetLastError());
+        if (wchunks > 1) {
+            k_sum_chunks<<<(unsigned)((B + 255) / 256), 256, 0, stream>>>(w.partial, B, wchunks, out);
+            HIP_TRY(hipGetLastError());
+        }
+        return QP_OK;
+    }
     if (walkable && dt->kind == QP_DT_U16) {
         V2WalkArgs w{};
         w.A = A;

@@ -1,5 +1,5 @@
 """Times the gate-ordered (sparse-partition) cost on the benchmark circuit, visit by visit and (16-bit table, 1024
-partitions or more) as a row walk: time_v2.py [B]"""
+partitions or more) as a row walk: time_v2.py [B [Q T mesh_x mesh_y]]"""
 import os
 import random
 import sys
@@ -18,15 +18,15 @@ from quantum_simulator_amd.timeslices import CircuitIR  # noqa: E402
 def main():
     dev = torch.device("cuda", 0)
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-    Q, T = 1024, 1000
+    Q, T, nx, ny = (int(x) for x in sys.argv[2:6]) if len(sys.argv) > 5 else (1024, 1000, 15, 17)
     q0, q1, _ = layered_gate_arrays(Q, T, 0.5, seed=2025)
     ir = CircuitIR.from_gate_tables(Q, q0, q1)
     eng = Engine(dev)
     forms = (("row walk where it applies", DeviceCircuit(ir, dev)), ("visit by visit", DeviceCircuit(ir, dev, visit_mask=False)))
-    A = make_partitions(torch, dev, B, ir.T, Q, forms[0][1].ldq, 255, 8, 0.95, seed=777)
+    A = make_partitions(torch, dev, B, ir.T, Q, forms[0][1].ldq, nx * ny, 8, 0.95, seed=777)
     random.seed(1234)
     for wr in ((2.0, 2.0), (1.0, 3.0)):
-        arch = multicore(15, 17, ncm_qubits=4, ncp_qubits=8, edge_weight_range=wr, network_type="mesh")
+        arch = multicore(nx, ny, ncm_qubits=4, ncp_qubits=8, edge_weight_range=wr, network_type="mesh")
         nodes, eu, ev, w = graph_tables(arch.network)
         dt = DistanceTable(apsp(len(nodes), eu, ev, w), dev)
         outs = []
