@@ -2078,6 +2078,7 @@ struct V2WalkArgs {
     const int32_t* sep;
     int32_t nE, lpr, G;
     int64_t ngroups;
+    int32_t id_bits, rep_shift;  // k_cost_v2_walk_parts: table index = from << id_bits | to; 2^rep_shift copies of every entry
 };
 
 template <bool V4, int AHEAD>
@@ -2211,31 +2212,41 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v2_walk(V2WalkArgs p) {
 // partition * ldq + piece * 16); slice t's gates are the same for all G partitions, so lane (partition g, slot k) takes
 // gates k, k + ldq / 16, ... of the slice against its own partition's row: every gate instruction serves 64 (gate,
 // partition) pairs.  Gates come from the edge records (slice order, no padding), the first kWalkGateChunks chunks of a
-// slice loaded together with the row.  Tables: 16-bit at pitch 256 (row and column 255 zero); fp64 of up to 64 cores
-// at pitch 256 followed by a zero entry that indices of absent sources are clamped onto.
+// slice loaded together with the row.  Table in LDS: index = from << k | to on the low k bits of the core ids, 2^k > C, so
+// 0xFF (no core) lands on row / column 2^k - 1, which is zero like the diagonal; every entry is stored 2^r times side
+// by side (16-bit entries widened to dwords, except at k = 8 where there is no room) and a lane reads copy
+// lane & (2^r - 1): with 32 dword copies or 16 fp64 copies (up to 31 cores) the look-ups of an instruction can never
+// meet in a bank, with fewer only the lanes that share a copy can.
 constexpr int kWalkGateChunks = 6;
 constexpr int kWalkPartsLds = 1024 + 768;  // per wave: the strip, then 64 sums and 64 error flags
 
-template <int KIND, bool V4, int AHEAD>
+template <int KIND, bool V4, int AHEAD, bool NATIVE16 = false>
 __global__ __launch_bounds__(kV3Threads) void k_cost_v2_walk_parts(V2WalkArgs p) {
     extern __shared__ __align__(16) uint8_t smem[];
     using E = typename Tab<KIND>::elem;
     using Acc = typename Tab<KIND>::acc;
+    using S = typename std::conditional<KIND == QP_DT_F64, double, typename std::conditional<NATIVE16, uint16_t, uint32_t>::type>::type;
+    typedef __attribute__((address_space(3))) const S lds_s;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-    const int nrows = KIND == QP_DT_U16 ? 256 : p.C;   // table rows staged; then one zero entry (fp64)
-    const uint32_t cap = (uint32_t)nrows << 8;          // index of the zero entry
+    const int kb = p.id_bits, rs = p.rep_shift;
+    const int nslots = (1 << (2 * kb)) << rs;
     {
         const E* src = static_cast<const E*>(p.table);
-        E* dst = reinterpret_cast<E*>(smem);
-        for (int k = threadIdx.x; k < nrows * 256 + 2; k += blockDim.x) {
-            const int r = k >> 8, c = k & 255;
-            dst[k] = (r < p.C && c < p.C) ? src[r * p.C + c] : E(0);
+        S* dst = reinterpret_cast<S*>(smem);
+        for (int k = threadIdx.x; k < nslots; k += blockDim.x) {
+            const int idx = k >> rs, r = idx >> kb, c = idx & ((1 << kb) - 1);
+            dst[k] = (r < p.C && c < p.C) ? (S)src[r * p.C + c] : S(0);
         }
         __syncthreads();
     }
-    const E* tab = reinterpret_cast<const E*>(smem);
-    const size_t tab_bytes = (((size_t)nrows * 256 + 2) * sizeof(E) + 15) & ~(size_t)15;
+    const size_t tab_bytes = (size_t)nslots * sizeof(S);
+    const uint32_t low = (1u << kb) - 1u;
+    const uint32_t mask_to = low * 0x00010001u, mask_from = (low << kb) * 0x00010001u;
+    const int step_log = rs + (sizeof(S) == 8 ? 3 : sizeof(S) == 4 ? 2 : 1);
+    const uint32_t step = 1u << step_log;  // bytes from an entry's copies to the next entry's
+    // LDS address of this lane's copy of entry 0
+    const uint32_t tlane = (uint32_t)(uintptr_t)(lds_u8*)smem + (uint32_t)(lane & ((1 << rs) - 1)) * (uint32_t)sizeof(S);
     const int ldq = p.ldq, lpr = p.lpr, G = p.G;
     uint8_t* strip = smem + tab_bytes + (size_t)wave * kWalkPartsLds;
     const bool lane_on = lane < G * lpr;
@@ -2243,23 +2254,25 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v2_walk_parts(V2WalkArgs p)
     const uint32_t lane_mask = lane_on ? ~0u : 0u;
     const uint32_t goff = (uint32_t)(g * ldq);
     auto at = [&](uint32_t from, uint32_t to) -> Acc {
-        const uint32_t idx = (from << 8) | to;
-        if constexpr (KIND == QP_DT_U16) return tab[idx];
-        else return tab[min(idx, cap)];
+        const uint32_t idx = ((from & low) << kb) | (to & low);
+        return (Acc) * (lds_s*)(uintptr_t)(tlane + (idx << step_log));
     };
-    const uint32_t tbase = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_u8*)smem);
-    // four (from, to) pairs of a dword: from << 8 | to in 16-bit halves; fp64: both halves clamped onto the zero entry
+    // the two entries whose indices are the 16-bit halves of x
+    auto two = [&](uint32_t x, S& e0, S& e1) {
+        uint32_t a0, a1;
+        asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[0,0,0,0]" : "=v"(a0) : "v"(x), "s"(step), "v"(tlane));
+        asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(a1) : "v"(x), "s"(step), "v"(tlane));
+        e0 = *(lds_s*)(uintptr_t)a0;
+        e1 = *(lds_s*)(uintptr_t)a1;
+    };
+    // four (from, to) pairs of a dword: from << 8 | to in 16-bit halves, squeezed to from << k | to on the ids' low k bits
     auto four = [&](uint32_t from, uint32_t to) -> Acc {
-        uint32_t k01 = __builtin_amdgcn_perm(from, to, 0x05010400u), k23 = __builtin_amdgcn_perm(from, to, 0x07030602u);
-        if constexpr (KIND != QP_DT_U16) {
-            typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-            const u16x2 lim = {(unsigned short)cap, (unsigned short)cap};
-            k01 = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, k01), lim));
-            k23 = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, k23), lim));
-        }
-        E e0, e1, e2, e3;
-        entries_at_halves<E>(k01, tbase, e0, e1);
-        entries_at_halves<E>(k23, tbase, e2, e3);
+        const uint32_t k01 = __builtin_amdgcn_perm(from, to, 0x05010400u), k23 = __builtin_amdgcn_perm(from, to, 0x07030602u);
+        const uint32_t x01 = ((k01 >> (8 - kb)) & mask_from) | (k01 & mask_to);
+        const uint32_t x23 = ((k23 >> (8 - kb)) & mask_from) | (k23 & mask_to);
+        S e0, e1, e2, e3;
+        two(x01, e0, e1);
+        two(x23, e2, e3);
         return ((Acc)e0 + (Acc)e1) + ((Acc)e2 + (Acc)e3);
     };
     const uint32_t* words = reinterpret_cast<const uint32_t*>(p.edges);  // records of 8 bytes: the pair is dword 0
@@ -2278,9 +2291,17 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v2_walk_parts(V2WalkArgs p)
             const uint4 m = *reinterpret_cast<const uint4*>(p.vmask + (size_t)min(row, T - 1) * ldq + piece * 16);
             return make_uint4(m.x & lane_mask, m.y & lane_mask, m.z & lane_mask, m.w & lane_mask);
         };
-        // gate `piece + c * lpr` of the slice, or a later slice's (the consumer checks the count)
-        auto fetch_gate = [&](int row, int c) -> uint32_t {
-            return words[2 * (size_t)min(p.sep[min(row, T - 1)] + c * lpr + piece, last_edge)];
+        // Slice starts in the edge records.  As scalar loads each would be waited for together with every LDS
+        // operation in flight; so they are loaded through an index the compiler cannot prove uniform, stay in vector
+        // registers, travel with the ring and are made scalar where they are used: the start of slice
+        // row + AHEAD + 1 is requested a row before it is needed.
+        int opaque_zero = 0;
+        asm volatile("" : "+v"(opaque_zero));
+        auto slice_start = [&](int row) -> int { return p.sep[min(row, T) + opaque_zero]; };
+        // gate `piece + c * lpr` of the slice that starts at `start`, or a later slice's (the consumer checks the count)
+        auto fetch_gate = [&](int start, int c) -> uint32_t {
+            const uint32_t off = min((uint32_t)(start + c * lpr + piece), (uint32_t)last_edge) * 8u;  // 32-bit offset from a uniform base
+            return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(words) + off);
         };
         uint32_t st[4];
         walk_state_at(part, p.vprev, r0, ldq, piece * 16, st);
@@ -2289,12 +2310,18 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v2_walk_parts(V2WalkArgs p)
         bool bad = false;
         uint4 ring[AHEAD], mring[AHEAD];
         uint32_t gring[AHEAD][kWalkGateChunks];
+        int sring[AHEAD], ering[AHEAD];
+        int sp_next = slice_start(r0);
 #pragma unroll
         for (int k = 0; k < AHEAD; ++k) {
+            sring[k] = sp_next;
+            sp_next = slice_start(r0 + k + 1);
+            ering[k] = sp_next;
             ring[k] = fetch_row(r0 + k);
             mring[k] = fetch_mask(r0 + k);
+            const int start = __builtin_amdgcn_readfirstlane(sring[k]);
 #pragma unroll
-            for (int c = 0; c < kWalkGateChunks; ++c) gring[k][c] = fetch_gate(r0 + k, c);
+            for (int c = 0; c < kWalkGateChunks; ++c) gring[k][c] = fetch_gate(start, c);
         }
         for (int g0 = r0; g0 < T; g0 += AHEAD) {
 #pragma unroll
@@ -2305,14 +2332,21 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v2_walk_parts(V2WalkArgs p)
                 uint32_t gates[kWalkGateChunks];
 #pragma unroll
                 for (int c = 0; c < kWalkGateChunks; ++c) gates[c] = gring[k][c];
-                ring[k] = fetch_row(row + AHEAD);
-                mring[k] = fetch_mask(row + AHEAD);
+                const int e0 = __builtin_amdgcn_readfirstlane(sring[k]);
+                const int slice_gates = __builtin_amdgcn_readfirstlane(ering[k]) - e0;
+                {
+                    const int sp_here = sp_next;             // start of slice row + AHEAD, asked for a row ago
+                    sp_next = slice_start(row + AHEAD + 1);  // used a row from now
+                    sring[k] = sp_here;
+                    ering[k] = sp_next;
+                    ring[k] = fetch_row(row + AHEAD);
+                    mring[k] = fetch_mask(row + AHEAD);
+                    const int start = __builtin_amdgcn_readfirstlane(sp_here);
 #pragma unroll
-                for (int c = 0; c < kWalkGateChunks; ++c) gring[k][c] = fetch_gate(row + AHEAD, c);
+                    for (int c = 0; c < kWalkGateChunks; ++c) gring[k][c] = fetch_gate(start, c);
+                }
 
                 if (lane_on) *reinterpret_cast<uint4*>(strip + lane * 16) = cur;
-                const int e0 = p.sep[row];
-                const int slice_gates = p.sep[row + 1] - e0;
                 const int mine = slice_gates - piece;  // gates c * lpr < mine are this lane's
                 uint32_t au[kWalkGateChunks], av[kWalkGateChunks];
 #pragma unroll
@@ -2331,26 +2365,26 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v2_walk_parts(V2WalkArgs p)
                 if (f1 != cur.y) acc += V4 ? four(cur.y, f1) : four(f1, cur.y);
                 if (f2 != cur.z) acc += V4 ? four(cur.z, f2) : four(f2, cur.z);
                 if (f3 != cur.w) acc += V4 ? four(cur.w, f3) : four(f3, cur.w);
-                if ((bytes_ff(cur.x & vm.x) | bytes_ff(cur.y & vm.y) | bytes_ff(cur.z & vm.z) | bytes_ff(cur.w & vm.w)) != 0)
-                    bad = bad || walk_lost(vm.x, l0, cur.x) || walk_lost(vm.y, l1, cur.y) || walk_lost(vm.z, l2, cur.z) ||
-                          walk_lost(vm.w, l3, cur.w);
+                // a visited byte with its top bit set may be 0xFF: only then the byte tests
+                if (((cur.x & vm.x) | (cur.y & vm.y) | (cur.z & vm.z) | (cur.w & vm.w)) & 0x80808080u) {
+                    if ((bytes_ff(cur.x & vm.x) | bytes_ff(cur.y & vm.y) | bytes_ff(cur.z & vm.z) | bytes_ff(cur.w & vm.w)) != 0)
+                        bad = bad || walk_lost(vm.x, l0, cur.x) || walk_lost(vm.y, l1, cur.y) || walk_lost(vm.z, l2, cur.z) ||
+                              walk_lost(vm.w, l3, cur.w);
+                }
                 l0 = (vm.x & cur.x) | (~vm.x & l0);
                 l1 = (vm.y & cur.y) | (~vm.y & l1);
                 l2 = (vm.z & cur.z) | (~vm.z & l2);
                 l3 = (vm.w & cur.w) | (~vm.w & l3);
-                uint32_t top = 0, differ = 0;
+                uint32_t top = 0;
 #pragma unroll
-                for (int c = 0; c < kWalkGateChunks; ++c) {
-                    top = max(top, max(au[c], av[c]));
-                    differ |= au[c] ^ av[c];
-                }
+                for (int c = 0; c < kWalkGateChunks; ++c) top = max(top, max(au[c], av[c]));
                 if (top == 0xFFu && p.gate_errors) {
 #pragma unroll
                     for (int c = 0; c < kWalkGateChunks; ++c) bad = bad || (gates[c] != 0u && max(au[c], av[c]) == 0xFFu);
                 }
-                if (differ != 0) {
 #pragma unroll
-                    for (int c = 0; c < kWalkGateChunks; ++c) acc += at(au[c], av[c]);
+                for (int c = 0; c < kWalkGateChunks; ++c) {
+                    if (c * lpr < slice_gates) acc += at(au[c], av[c]);  // the same for the whole wave
                 }
                 for (int c = kWalkGateChunks; c * lpr < mine && lane_on; ++c) {
                     const uint32_t w = words[2 * (size_t)(e0 + c * lpr + piece)];
@@ -3135,11 +3169,19 @@ extern "C" int qp_slice_cost_v2(const QpCircuit* circ, const QpDTable* dt, const
             w.partial = static_cast<double*>(workspace);
         }
         const bool v4 = flags == QP_V4;
+        // ids squeezed to k bits, 2^k > C (0xFF becomes 2^k - 1); as many copies of every entry as fit 128 KB, up to
+        // one per bank (32 dwords, 16 doubles); a 16-bit table of 128 cores or more stays 16 bits wide, one copy
+        int kb = 1;
+        while ((1 << kb) <= dt->C) ++kb;
+        const bool f64 = dt->kind == QP_DT_F64, native16 = !f64 && kb == 8;
+        const int esz_log = f64 ? 3 : native16 ? 1 : 2;
+        w.id_bits = kb;
+        w.rep_shift = std::max(0, std::min(f64 ? 4 : native16 ? 0 : 5, 17 - 2 * kb - esz_log));
         void (*walk)(V2WalkArgs) =
-            dt->kind == QP_DT_U16 ? (v4 ? k_cost_v2_walk_parts<QP_DT_U16, true, 3> : k_cost_v2_walk_parts<QP_DT_U16, false, 3>)
-                                  : (v4 ? k_cost_v2_walk_parts<QP_DT_F64, true, 3> : k_cost_v2_walk_parts<QP_DT_F64, false, 3>);
-        const size_t entries = (size_t)(dt->kind == QP_DT_U16 ? 256 : dt->C) * 256 + 2;
-        const size_t lds = ((entries * (dt->kind == QP_DT_U16 ? 2 : 8) + 15) & ~(size_t)15) + (size_t)kV3Waves * kWalkPartsLds;
+            f64 ? (v4 ? k_cost_v2_walk_parts<QP_DT_F64, true, 3> : k_cost_v2_walk_parts<QP_DT_F64, false, 3>)
+            : native16 ? (v4 ? k_cost_v2_walk_parts<QP_DT_U16, true, 3, true> : k_cost_v2_walk_parts<QP_DT_U16, false, 3, true>)
+                       : (v4 ? k_cost_v2_walk_parts<QP_DT_U16, true, 3> : k_cost_v2_walk_parts<QP_DT_U16, false, 3>);
+        const size_t lds = ((((size_t)1 << (2 * kb)) << w.rep_shift) << esz_log) + (size_t)kV3Waves * kWalkPartsLds;
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(walk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const unsigned grid = (unsigned)std::min<int64_t>(wcus, (w.nitems + kV3Waves - 1) / kV3Waves);
         walk<<<grid, kV3Threads, lds, stream>>>(w);
