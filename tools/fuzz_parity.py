@@ -128,6 +128,13 @@ def main():
         if os.environ.get("QP_FUZZ_KIND"):  # one kind of case only
             kind = int(os.environ["QP_FUZZ_KIND"])
         if kind == 12:  # gate-ordered cost as a row walk: whole partitions or chunks of slices, looked up or pair-counted
+            if pick(0, 1):  # rows of at most 512 bytes: several partitions per wave step, from 64 MB on
+                Q = pick(8, 512)
+                T = pick(20, 250)
+                B = (1 << 26) // ((Q + 15) // 16 * 16) // T + pick(1, 100)
+                C = pick(2, 255)
+                integer = bool(pick(0, 1)) or C > 64
+                return "cost_v2_row_walk", TC.test_cost_v2_row_walk, (gpu, Q, T, C, B, float(rng.choice([0.0, 0.1, 0.3])), integer)
             if pick(0, 1):
                 B, T = pick(1024, 1400), pick(1, 40)
             else:
