@@ -2122,7 +2122,13 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v2_walk(V2WalkArgs p) {
             const uint4 m = *reinterpret_cast<const uint4*>(p.vmask + (size_t)min(row, T - 1) * ldq + lane16);
             return make_uint4(m.x & lane_mask, m.y & lane_mask, m.z & lane_mask, m.w & lane_mask);
         };
-        auto fetch_gate = [&](int row, int c) -> uint32_t { return sched_lane[p.sptr[min(row, T - 1)] + c * kWave]; };
+        // slice starts in the gate list: vector loads through an index the compiler cannot prove uniform, carried
+        // with the ring and made scalar where they are used (as scalar loads each would be waited for together with
+        // every LDS operation in flight); the start of slice row + AHEAD + 1 is requested a row before it is needed
+        int opaque_zero = 0;
+        asm volatile("" : "+v"(opaque_zero));
+        auto slice_start = [&](int row) -> int { return p.sptr[min(row, T) + opaque_zero]; };
+        auto fetch_gate = [&](int start, int c) -> uint32_t { return sched_lane[start + c * kWave]; };
         uint32_t st[4];
         walk_state_at(base, p.vprev, r0, ldq, lane16, st);
         uint32_t l0 = st[0], l1 = st[1], l2 = st[2], l3 = st[3];
@@ -2130,12 +2136,18 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v2_walk(V2WalkArgs p) {
         bool bad = false;
         uint4 ring[AHEAD], mring[AHEAD];
         uint32_t gring[AHEAD][kRowEdgeChunks];
+        int sring[AHEAD], ering[AHEAD];
+        int sp_next = slice_start(r0);
 #pragma unroll
         for (int k = 0; k < AHEAD; ++k) {
+            sring[k] = sp_next;
+            sp_next = slice_start(r0 + k + 1);
+            ering[k] = sp_next;
             ring[k] = fetch_row(r0 + k);
             mring[k] = fetch_mask(r0 + k);
+            const int start = __builtin_amdgcn_readfirstlane(sring[k]);
 #pragma unroll
-            for (int c = 0; c < kRowEdgeChunks; ++c) gring[k][c] = fetch_gate(r0 + k, c);
+            for (int c = 0; c < kRowEdgeChunks; ++c) gring[k][c] = fetch_gate(start, c);
         }
         for (int g0 = r0; g0 < T; g0 += AHEAD) {
             uint32_t acc = 0;  // at most AHEAD * (16 + gates of a slice / 64 + 1) terms below 2^16 each
@@ -2147,14 +2159,21 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v2_walk(V2WalkArgs p) {
                 uint32_t gates[kRowEdgeChunks];
 #pragma unroll
                 for (int c = 0; c < kRowEdgeChunks; ++c) gates[c] = gring[k][c];
-                ring[k] = fetch_row(row + AHEAD);
-                mring[k] = fetch_mask(row + AHEAD);
+                const int s0 = __builtin_amdgcn_readfirstlane(sring[k]);
+                const int nch = (__builtin_amdgcn_readfirstlane(ering[k]) - s0) / kWave;
+                {
+                    const int sp_here = sp_next;             // start of slice row + AHEAD, asked for a row ago
+                    sp_next = slice_start(row + AHEAD + 1);  // used a row from now
+                    sring[k] = sp_here;
+                    ering[k] = sp_next;
+                    ring[k] = fetch_row(row + AHEAD);
+                    mring[k] = fetch_mask(row + AHEAD);
+                    const int start = __builtin_amdgcn_readfirstlane(sp_here);
 #pragma unroll
-                for (int c = 0; c < kRowEdgeChunks; ++c) gring[k][c] = fetch_gate(row + AHEAD, c);
+                    for (int c = 0; c < kRowEdgeChunks; ++c) gring[k][c] = fetch_gate(start, c);
+                }
 
                 if (lane_on) *reinterpret_cast<uint4*>(strip + lane * 16) = cur;
-                const int s0 = p.sptr[row];
-                const int nch = (p.sptr[row + 1] - s0) / kWave;
                 uint32_t au[kRowEdgeChunks], av[kRowEdgeChunks];
 #pragma unroll
                 for (int c = 0; c < kRowEdgeChunks; ++c) {
@@ -3131,19 +3150,21 @@ extern "C" int qp_slice_cost_v2(const QpCircuit* circ, const QpDTable* dt, const
     // A circuit that visits most of every row (over 128 qubits a slice, where reading whole rows beats gathering the
     // visited bytes), enough rows to fill the GPU: the row walk.  16-bit tables are looked up (integer sums); fp64 tables
     // that are symmetric to rounding are applied to core-pair counts; other fp64 tables stay with the visits.
+    // (visit_prev holds slice numbers in 16 bits)
+    const int16_t* const vprev_ok = circ->T <= 32767 ? circ->visit_prev : nullptr;
     const bool walkable = ldq > 512 && ldq <= 1024 && circ->visit_mask && circ->visit_mask_ldq == ldq &&
                           circ->edges_sched && circ->sched_ptr && (int64_t)circ->nV >= (int64_t)128 * T &&
-                          (circ->visit_prev ? (int64_t)B * T >= 65536 : B >= 1024);
+                          (vprev_ok ? (int64_t)B * T >= 65536 : B >= 1024);
     const int wcus = qp::device_cus();
     // rows of at most 512 bytes: the same walk with G partitions per wave step
     const int32_t wlpr = ldq / 16, wG = wlpr > 0 && wlpr <= 32 ? kWave / wlpr : 0;
-    if (wG >= 2 && circ->visit_mask && circ->visit_mask_ldq == ldq && circ->visit_prev && circ->edges && circ->slice_edge_ptr &&
+    if (wG >= 2 && circ->visit_mask && circ->visit_mask_ldq == ldq && vprev_ok && circ->edges && circ->slice_edge_ptr &&
         circ->nE > 0 && (int64_t)circ->nV * 8 >= (int64_t)T * ldq && B >= wG && (int64_t)B * T * ldq >= ((int64_t)1 << 26) &&
         (dt->kind == QP_DT_U16 || dt->C <= 64)) {
         V2WalkArgs w{};
         w.A = A;
         w.vmask = circ->visit_mask;
-        w.vprev = circ->visit_prev;
+        w.vprev = vprev_ok;
         w.edges = circ->edges;
         w.sep = circ->slice_edge_ptr;
         w.nE = circ->nE;
@@ -3196,7 +3217,7 @@ extern "C" int qp_slice_cost_v2(const QpCircuit* circ, const QpDTable* dt, const
         V2WalkArgs w{};
         w.A = A;
         w.vmask = circ->visit_mask;
-        w.vprev = circ->visit_prev;
+        w.vprev = vprev_ok;
         w.sched = circ->edges_sched;
         w.sptr = circ->sched_ptr;
         w.table = dt->table;
@@ -3208,7 +3229,7 @@ extern "C" int qp_slice_cost_v2(const QpCircuit* circ, const QpDTable* dt, const
         w.gate_errors = flags != QP_V1;
         // whole partitions when there are two or more per wave the GPU holds, else chunks of 64 slices or more
         int32_t wchunks = 1;
-        if (circ->visit_prev)
+        if (vprev_ok)
             wchunks = (int32_t)std::max<int64_t>(1, std::min<int64_t>(T / 64, ((int64_t)wcus * kV3Waves * 2 + B - 1) / B));
         w.rows_per_item = (T + wchunks - 1) / wchunks;
         wchunks = (T + w.rows_per_item - 1) / w.rows_per_item;
@@ -3232,14 +3253,14 @@ extern "C" int qp_slice_cost_v2(const QpCircuit* circ, const QpDTable* dt, const
         }
         return QP_OK;
     }
-    if (walkable && dt->kind == QP_DT_F64 && dt->symmetric && dt->C >= 2 && circ->visit_prev) {
+    if (walkable && dt->kind == QP_DT_F64 && dt->symmetric && dt->C >= 2 && vprev_ok) {
         // as the dense cost does it: whole workgroups take an item, about 8 items per workgroup
         V3Args q{};
         q.A = A;
         q.edges_sched = circ->edges_sched;
         q.sptr = circ->sched_ptr;
         q.vmask = circ->visit_mask;
-        q.vprev = circ->visit_prev;
+        q.vprev = vprev_ok;
         q.B = B;
         q.T = T;
         q.Tp = Tp;
