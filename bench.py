@@ -514,6 +514,37 @@ def main():
         activity = {"kernel": "k_cost_v3_pairs<4, true>" if 512 < dc.ldq <= 1024 else "k_core_activity", "partitions": nb, "kernel_ms": ms, "evals_per_s": nb * ir.T / (ms * 1e-3),
                     "gbs": nb * ir.T * dc.ldq / (ms * 1e-3) / 1e9, "events_in_partition_0": int(counts[0].sum().item())}
         del Asub, counts
+    gate_ordered = None
+    if not args.no_qubo and world == 1:
+        # the gate-ordered cost (BFS_placer.py:202-239) of a slice of the batch on a 15 x 17 mesh (that cost keeps core
+        # id 255 for "qubit absent"): read row by row against visit by visit
+        try:
+            from quantum_simulator_amd.engine import QP_V2
+            random.seed(weight_seed)
+            arch255 = multicore(15, 17, ncm_qubits=4, ncp_qubits=cap, edge_weight_range=(1.0, 3.0), network_type="mesh")
+            nodes, eu, ev, w = graph_tables(arch255.network)
+            dt255 = DistanceTable(apsp(len(nodes), eu, ev, w), dev)
+            nb = min(B, 1024)
+            Asub = A[:nb, :ir.T].clamp(max=254).contiguous()
+            gate_ordered = {"partitions": nb, "cores": 255, "table": "f64, symmetric to rounding"}
+            for key, circuit in (("row_walk", dc), ("visit_by_visit", DeviceCircuit(ir, dev, visit_mask=False))):
+                o2 = torch.empty(nb, dtype=torch.float64, device=dev)
+                for _ in range(2):
+                    eng.cost_v2(circuit, dt255, Asub, QP_V2, out=o2)
+                torch.cuda.synchronize(dev)
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record(torch.cuda.current_stream(dev))
+                for _ in range(5):
+                    eng.cost_v2(circuit, dt255, Asub, QP_V2, out=o2)
+                ev1.record(torch.cuda.current_stream(dev))
+                torch.cuda.synchronize(dev)
+                ms = ev0.elapsed_time(ev1) / 5
+                gate_ordered[key] = {"kernel": "k_cost_v2_pairs<4>" if key == "row_walk" else "k_cost_v2<0, false, 256>",
+                                     "ms": ms, "evals_per_s": nb * ir.T / (ms * 1e-3), "gbs": nb * ir.T * dc.ldq / (ms * 1e-3) / 1e9,
+                                     "mean_cost": float(o2.mean().item())}
+            del Asub
+        except Exception as exc:  # noqa: BLE001 - a side table must not cost the headline line
+            gate_ordered = {"error": f"{type(exc).__name__}: {exc}"}
     qubo = None
     if not args.no_qubo:
         del A
@@ -556,7 +587,7 @@ def main():
                        "seeds": {"circuit": circ_seed, "weights": weight_seed, "partitions": "777+rank"},
                        "table": primary["table"]},
             "roofline": primary["roofline"], "mean_cost": primary["mean_cost"], "min_cost": primary["min_cost"],
-            "reduce_ms": primary["reduce_ms"], "gtrhqa_place": place, "cost_matrix": cm, "core_activity": activity, "qubo": qubo,
+            "reduce_ms": primary["reduce_ms"], "gtrhqa_place": place, "cost_matrix": cm, "core_activity": activity, "gate_ordered_cost": gate_ordered, "qubo": qubo,
             "shipped_circuits": shipped, "shipped_circuits_cost_at_scale": shipped_cost, "broken_links": broken,
         }
         # HBM bytes per launch as measured with rocprofv3 PMC counters in a separate run of this workload
