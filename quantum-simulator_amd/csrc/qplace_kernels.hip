@@ -2235,7 +2235,7 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v2_walk(V2WalkArgs p) {
 // 0xFF (no core) lands on row / column 2^k - 1, which is zero like the diagonal; every entry is stored 2^r times side
 // by side (16-bit entries widened to dwords, except at k = 8 where there is no room) and a lane reads copy
 // lane & (2^r - 1): with 32 dword copies or 16 fp64 copies (up to 31 cores) the look-ups of an instruction can never
-// meet in a bank, with fewer only the lanes that share a copy can.
+// meet in a bank, with fewer only the lanes that share a copy can.  An fp64 table fits up to 127 cores (k = 7, 128 KB).
 constexpr int kWalkGateChunks = 6;
 constexpr int kWalkPartsLds = 1024 + 768;  // per wave: the strip, then 64 sums and 64 error flags
 
@@ -3160,7 +3160,7 @@ extern "C" int qp_slice_cost_v2(const QpCircuit* circ, const QpDTable* dt, const
     const int32_t wlpr = ldq / 16, wG = wlpr > 0 && wlpr <= 32 ? kWave / wlpr : 0;
     if (wG >= 2 && circ->visit_mask && circ->visit_mask_ldq == ldq && vprev_ok && circ->edges && circ->slice_edge_ptr &&
         circ->nE > 0 && (int64_t)circ->nV * 8 >= (int64_t)T * ldq && B >= wG && (int64_t)B * T * ldq >= ((int64_t)1 << 26) &&
-        (dt->kind == QP_DT_U16 || dt->C <= 64)) {
+        (dt->kind == QP_DT_U16 || dt->C <= 127)) {
         V2WalkArgs w{};
         w.A = A;
         w.vmask = circ->visit_mask;

@@ -454,10 +454,10 @@ def test_cost_v2_random(gpu, Q, T, C, B, integer):
     (513, 9, 2, 1024, 0.2, True), (777, 130, 64, 1024, 0.1, True), (1024, 260, 200, 260, 0.1, True),
     (1024, 37, 255, 2000, 0.05, False), (1000, 300, 16, 230, 0.3, False), (600, 129, 100, 520, 0.0, False),
     (513, 70, 2, 1024, 0.2, False),
-    # rows of at most 512 bytes: several partitions per wave step (16-bit tables; fp64 up to 64 cores)
+    # rows of at most 512 bytes: several partitions per wave step (16-bit tables; fp64 up to 127 cores)
     (63, 260, 64, 4100, 0.1, True), (63, 260, 64, 4100, 0.1, False), (200, 220, 255, 1500, 0.2, True),
     (512, 120, 30, 1100, 0.0, False), (17, 240, 9, 9001, 0.0, True), (100, 250, 16, 2500, 0.3, False),
-    (300, 30, 100, 7400, 0.1, True)])
+    (300, 30, 100, 7400, 0.1, True), (200, 220, 127, 1500, 0.2, False), (256, 100, 65, 2700, 0.0, False)])
 def test_cost_v2_row_walk(gpu, Q, T, C, B, drop, integer):
     """Batches on a circuit that visits most qubits in most slices are walked row by row (16-bit tables looked up,
     symmetric fp64 tables through core-pair counts; few partitions in chunks of slices): equal to the visit-by-visit

@@ -133,7 +133,7 @@ def main():
                 T = pick(20, 250)
                 B = (1 << 26) // ((Q + 15) // 16 * 16) // T + pick(1, 100)
                 C = pick(2, 255)
-                integer = bool(pick(0, 1)) or C > 64
+                integer = bool(pick(0, 1)) or C > 127
                 return "cost_v2_row_walk", TC.test_cost_v2_row_walk, (gpu, Q, T, C, B, float(rng.choice([0.0, 0.1, 0.3])), integer)
             if pick(0, 1):
                 B, T = pick(1024, 1400), pick(1, 40)
