@@ -126,8 +126,9 @@ class DeviceCircuit:
         if grouped is not None:
             self._gptr, self._gsched = _to_dev(grouped[0], self.device), _to_dev(grouped[1], self.device)
         # rows of up to 1024 bytes: which qubits every slice visits, for the row walk of the gate-ordered cost
-        # (visit_mask=False leaves it out: the cost is then always taken visit by visit)
-        self._vmask = _to_dev(ir.visit_mask(self.ldq), self.device) if visit_mask and self.ldq <= 1024 and ir.T else None
+        # (visit_mask=False leaves it out: the cost is then always taken visit by visit; so does a circuit whose
+        # mask would take more than 64 MB)
+        self._vmask = _to_dev(ir.visit_mask(self.ldq), self.device) if visit_mask and self.ldq <= 1024 and 0 < ir.T * self.ldq <= 1 << 26 else None
         self._vprev = _to_dev(ir.visit_prev(self.ldq), self.device) if self._vmask is not None and ir.T <= 32767 else None
         self.c = QpCircuit(ir.Q, ir.T, ir.nE, ir.nV, most, self.ldq if grouped is not None else 0,
                            self._sep.data_ptr(), self._edges.data_ptr(),
