@@ -86,13 +86,15 @@ typedef struct QpCircuit {
     const uint8_t* visit_mask;      /* optional, rows of up to 1024 bytes: [T][visit_mask_ldq] bytes, 0xFF where the
                                        qubit is an operand of some command of the slice (a visit of the gate-ordered
                                        walk), 0 elsewhere and in the padding; with it and edges_sched, large batches
-                                       of the gate-ordered cost are walked row by row instead of visit by visit */
+                                       of the gate-ordered cost are walked row by row instead of visit by visit;
+                                       with edges and slice_edge_ptr likewise for rows of at most 512 bytes (which
+                                       need visit_prev too); 16-byte aligned */
     int32_t visit_mask_ldq;         /* row pitch visit_mask was laid out for; 0 = none */
     int32_t reserved_;
     const int16_t* visit_prev;      /* optional with visit_mask, T <= 32767: [T][visit_mask_ldq], the last slice before
                                        slice t that visits the qubit, -1 if none; lets the walk start in the middle of
                                        a partition (small batches split into chunks of slices, fp64 tables counted
-                                       by core pair) */
+                                       by core pair); 32-byte aligned */
 } QpCircuit;
 
 /* Distance table as the kernels consume it. */
