@@ -126,6 +126,8 @@ extern "C" int qp_comm_matrix(const QpCircuit* circ, const uint8_t* A, int64_t B
     HIP_TRY(hipMemsetAsync(out, 0, (size_t)B * C * C * sizeof(int32_t), stream));
     HIP_TRY(hipMemsetAsync(status, 0, (size_t)B * sizeof(int32_t), stream));
     if (circ->nV == 0) return QP_OK;
+    // large batches on a circuit that visits most of every row: the pair counters of the row walk are the matrix
+    if (const int rc = qp::comm_matrix_pairs(circ, A, B, Tp, ldq, C, out, status, stream_); rc <= 0) return rc;
     if (!circ->visits) return qp::fail(QP_EINVAL, "qp_comm_matrix: circuit visit table missing");
     const dim3 grid((unsigned)((circ->nV + kThreads - 1) / kThreads), (unsigned)B);
     k_comm_matrix<<<grid, kThreads, 0, stream>>>(A, circ->visits, circ->nV, Tp, ldq, C, out, status);

@@ -30,6 +30,12 @@ int cost_matrix_resolved(int32_t kind, const double* tables, int32_t C, const in
 int core_activity_pairs(const QpCircuit* circ, const uint8_t* A, int64_t B, int32_t Tp, int32_t ldq, int32_t C,
                         uint64_t* out, void* stream);
 
+// qp_comm_matrix through the same pair counters, walking the partitions row by row (rows of 513 to 1024 bytes, a circuit
+// with visit_mask / visit_prev that visits most of every row): adds the counts to out[B][C][C] and sets status[b] where
+// the reference raises; both zeroed by the caller.  QP_OK, a negative code, or 1 when this form does not apply.
+int comm_matrix_pairs(const QpCircuit* circ, const uint8_t* A, int64_t B, int32_t Tp, int32_t ldq, int32_t C, int32_t* out,
+                      int32_t* status, void* stream);
+
 // The make-space step of qp_make_space on one assignment row and its occupancy counts.
 void make_space_row(uint8_t* a, int64_t* occ, int32_t Q, int32_t C, int32_t cap, const double* D);
 }  // namespace qp

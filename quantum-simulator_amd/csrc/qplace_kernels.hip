@@ -166,6 +166,8 @@ struct V3Args {
     unsigned long long* activity;  // k_cost_v3_pairs<., true>: per-core event counts [B][C] instead of a cost
     const uint8_t* vmask;          // k_cost_v2_pairs: [T][ldq] 0xFF where a slice visits the qubit
     const int16_t* vprev;          // k_cost_v2_pairs: [T][ldq] last slice before t that visits the qubit, -1 if none
+    int32_t* comm;                 // k_comm_matrix_pairs: [B][C][C] event counts, zeroed by the caller
+    int32_t* status;               // k_comm_matrix_pairs: [B], set to 1 where the reference raises
     int32_t gate_errors;           // k_cost_v2_pairs: non-zero = a counted gate with an operand on no core is an error
                                    // (V2, V4); zero = it adds nothing (V1)
     int32_t parts_per_item;  // k_cost_v3_groups: consecutive partitions a wave takes as one stream of steps (> 1 only
@@ -1138,6 +1140,22 @@ __device__ inline bool walk_lost(uint32_t m, uint32_t l, uint32_t c) {
         n += (((m >> (8 * j)) & 0xFFu) != 0 && ((c >> (8 * j)) & 0xFFu) == 0xFFu && ((l >> (8 * j)) & 0xFFu) != 0xFFu) ? 1 : 0;
     return n != 0;
 }
+// non-zero iff some byte of y is >= n (1 <= n <= 255; n is the same for the whole wave)
+__device__ inline uint32_t bytes_ge(uint32_t y, int n) {
+    const uint32_t low = y & 0x7F7F7F7Fu;
+    if (n <= 128) return ((low + (uint32_t)(128 - n) * 0x01010101u) | y) & 0x80808080u;
+    return (low + (uint32_t)(256 - n) * 0x01010101u) & y & 0x80808080u;
+}
+// a visited byte (mask m) of the row (c) that names a core outside 0 .. C - 1 (0xFF, no core, is not one)
+__device__ inline bool walk_stray(uint32_t m, uint32_t c, int C) {
+    int n = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t v = (c >> (8 * j)) & 0xFFu;
+        n += (((m >> (8 * j)) & 0xFFu) != 0 && v != 0xFFu && v >= (uint32_t)C) ? 1 : 0;
+    }
+    return n != 0;
+}
 // The cores the lane's 16 qubits (row bytes lane16 .. lane16 + 15) had at their last visit before slice r0, from
 // vprev[r0][q] = that slice or -1; 0xFF where there was none.  Sixteen byte gathers per lane, all in flight together.
 __device__ inline void walk_state_at(const uint8_t* base, const int16_t* vprev, int r0, int ldq, int lane16, uint32_t (&st)[4]) {
@@ -1160,10 +1178,37 @@ __device__ inline void walk_state_at(const uint8_t* base, const int16_t* vprev, 
     }
 }
 
+// The same pass for the core x core communication counts of the gate-ordered walk (Qubo_placer.py:208-245: every event
+// between two different cores adds one to M[a][b] and to M[b][a]); several items of a partition add into one matrix,
+// a partition that is one item stores into its (zeroed) matrix.
+template <int THREADS>
+__device__ inline void apply_pair_comm(uint32_t* cnt, int32_t* M, int C, bool only_writer) {
+    for (int k = threadIdx.x; k < kPairSlots; k += THREADS) {
+        const uint32_t n = cnt[k];
+        if (n) {
+            cnt[k] = 0;
+            const int r = k >> 8, col = k & 255;
+            const bool upper = col <= 128 + r;
+            const int hi = upper ? 128 + r : 127 - r, lo = upper ? col : 255 - col;
+            if (hi != lo && hi < C) {
+                if (only_writer) {
+                    M[hi * C + lo] = (int)n;
+                    M[lo * C + hi] = (int)n;
+                } else {
+                    atomicAdd(&M[hi * C + lo], (int)n);
+                    atomicAdd(&M[lo * C + hi], (int)n);
+                }
+            }
+        }
+    }
+}
+
 // WALK: the gate-ordered cost (V1 / V2 / V4; V2 and V4 differ only in the table the caller passes once it is symmetrised)
 // instead of the dense one: movement of the qubits a slice visits against their cores at their previous visit (see
 // k_cost_v2_walk), from the first row on; a wave's run starts from the state walk_state_at gathers.
-template <int AHEAD, bool ACTIVITY, bool WALK>
+// COMM (with WALK): the counts themselves are the result (apply_pair_comm); a visited qubit on a core outside 0 .. C - 1
+// is an error like an absent operand.
+template <int AHEAD, bool ACTIVITY, bool WALK, bool COMM = false>
 __device__ __forceinline__ void pairs_by_row(const V3Args& p) {
     extern __shared__ __align__(16) uint8_t smem[];
     const int lane = threadIdx.x & (kWave - 1);
@@ -1299,17 +1344,18 @@ __device__ __forceinline__ void pairs_by_row(const V3Args& p) {
                     const uint32_t g = sched_lane[s0 + c * kWave];
                     const uint32_t u = strip[g & 0xFFFFu], v = strip[g >> 16];
                     count_gates2(u, v);  // the upper halves are the pair (0, 0): a diagonal slot
-                    if constexpr (WALK) bad = bad || (p.gate_errors && g != 0u && max(u, v) == 0xFFu);
+                    if constexpr (COMM) bad = bad || (g != 0u && max(u, v) >= (uint32_t)p.C);
+                    else if constexpr (WALK) bad = bad || (p.gate_errors && g != 0u && max(u, v) == 0xFFu);
                 }
                 if constexpr (WALK) {
                     // a counted gate (padding words are zero) with an operand on no core
                     uint32_t top = 0;
 #pragma unroll
                     for (int c = 0; c < kRowEdgeChunks; ++c) top = max(top, max(au[c], av[c]));
-                    if (top == 0xFFu && p.gate_errors) {
+                    if (COMM ? top >= (uint32_t)p.C : (top == 0xFFu && p.gate_errors)) {
 #pragma unroll
                         for (int c = 0; c < kRowEdgeChunks; ++c)
-                            bad = bad || ((c < nch ? gates[c] : 0u) != 0u && max(au[c], av[c]) == 0xFFu);
+                            bad = bad || ((c < nch ? gates[c] : 0u) != 0u && max(au[c], av[c]) >= (COMM ? (uint32_t)p.C : 0xFFu));
                     }
                     // visited qubits against their cores at the previous visit; the others against themselves
                     const uint32_t f0 = (vm.x & p0) | (~vm.x & cur.x), f1 = (vm.y & p1) | (~vm.y & cur.y);
@@ -1318,7 +1364,14 @@ __device__ __forceinline__ void pairs_by_row(const V3Args& p) {
                     if (f1 != cur.y) count4(f1, cur.y);
                     if (f2 != cur.z) count4(f2, cur.z);
                     if (f3 != cur.w) count4(f3, cur.w);
-                    if ((bytes_ff(cur.x & vm.x) | bytes_ff(cur.y & vm.y) | bytes_ff(cur.z & vm.z) | bytes_ff(cur.w & vm.w)) != 0)
+                    if constexpr (COMM) {
+                        // a visited byte >= C (0xFF included): then the exact tests
+                        if ((bytes_ge(cur.x & vm.x, p.C) | bytes_ge(cur.y & vm.y, p.C) | bytes_ge(cur.z & vm.z, p.C) |
+                             bytes_ge(cur.w & vm.w, p.C)) != 0)
+                            bad = bad || walk_lost(vm.x, p0, cur.x) || walk_lost(vm.y, p1, cur.y) || walk_lost(vm.z, p2, cur.z) ||
+                                  walk_lost(vm.w, p3, cur.w) || walk_stray(vm.x, cur.x, p.C) || walk_stray(vm.y, cur.y, p.C) ||
+                                  walk_stray(vm.z, cur.z, p.C) || walk_stray(vm.w, cur.w, p.C);
+                    } else if ((bytes_ff(cur.x & vm.x) | bytes_ff(cur.y & vm.y) | bytes_ff(cur.z & vm.z) | bytes_ff(cur.w & vm.w)) != 0)
                         bad = bad || walk_lost(vm.x, p0, cur.x) || walk_lost(vm.y, p1, cur.y) || walk_lost(vm.z, p2, cur.z) ||
                               walk_lost(vm.w, p3, cur.w);
                     p0 = (vm.x & cur.x) | (~vm.x & p0);
@@ -1350,6 +1403,12 @@ __device__ __forceinline__ void pairs_by_row(const V3Args& p) {
                 if (g0 + k < w1) do_row(g0 + k, ring[k], mring[WALK ? k : 0], gring[k], sring[k], ering[k], false);
         }
         __syncthreads();
+        if constexpr (COMM) {
+            if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) p.status[b] = 1;
+            apply_pair_comm<kV3Threads>(cnt, p.comm + (size_t)b * p.C * p.C, p.C, p.rows_per_item >= p.T);
+            __syncthreads();  // every counter is read and zero again before the next item counts
+            continue;
+        }
         if constexpr (ACTIVITY) {
             apply_pair_activity<kV3Threads>(cnt, hist);
             __syncthreads();
@@ -1381,6 +1440,12 @@ __device__ __forceinline__ void pairs_by_row(const V3Args& p) {
 template <int AHEAD = kV3Ahead, bool ACTIVITY = false>
 __global__ __launch_bounds__(kV3Threads) void k_cost_v3_pairs(V3Args p) {
     pairs_by_row<AHEAD, ACTIVITY, false>(p);
+}
+
+// The communication-count matrix of the gate-ordered walk from the same counts.
+template <int AHEAD>
+__global__ __launch_bounds__(kV3Threads) void k_comm_matrix_pairs(V3Args p) {
+    pairs_by_row<AHEAD, false, true, true>(p);
 }
 
 // Cost V1 / V2 / V4 with an fp64 table that is symmetric to rounding, by core-pair counts.
@@ -3099,6 +3164,45 @@ int qp::core_activity_pairs(const QpCircuit* circ, const uint8_t* A, int64_t B, 
     q.nitems = (int64_t)chunks * B;
     const size_t lds = (size_t)kPairSlots * sizeof(uint32_t) + strips + kV3Waves * sizeof(double) + 256 * sizeof(uint32_t);
     if (lds > (size_t)kLdsBytes) return 1;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    kern<<<(unsigned)std::min<int64_t>(cus, q.nitems), kV3Threads, lds, stream>>>(q);
+    HIP_TRY(hipGetLastError());
+    return QP_OK;
+}
+
+int qp::comm_matrix_pairs(const QpCircuit* circ, const uint8_t* A, int64_t B, int32_t Tp, int32_t ldq, int32_t C,
+                          int32_t* out, int32_t* status, void* stream_) {
+    const int32_t T = circ->T;
+    // rows of 513 to 1024 bytes, a circuit that visits over 128 qubits per slice, enough rows for the GPU
+    if (ldq <= 512 || ldq > 1024 || ldq % 16 || T <= 0 || T > 32767 || reinterpret_cast<uintptr_t>(A) % 16 || !circ->visit_mask ||
+        circ->visit_mask_ldq != ldq || !circ->visit_prev || !circ->edges_sched || !circ->sched_ptr ||
+        (int64_t)circ->nV < (int64_t)128 * T || (int64_t)B * T < 16384)
+        return 1;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    V3Args q{};
+    q.A = A;
+    q.edges_sched = circ->edges_sched;
+    q.sptr = circ->sched_ptr;
+    q.vmask = circ->visit_mask;
+    q.vprev = circ->visit_prev;
+    q.B = B;
+    q.T = T;
+    q.Tp = Tp;
+    q.ldq = ldq;
+    q.Q = circ->Q;
+    q.C = C;
+    q.gate_errors = 1;
+    q.comm = out;
+    q.status = status;
+    const int cus = qp::device_cus();
+    // an item ends with a pass over all counters and up to two global updates per core pair that occurred: whole
+    // partitions (every matrix then has one writer, which stores instead of adding) unless that leaves most of the GPU
+    // idle; then about one item per workgroup
+    const int64_t want = ((int64_t)T * B + cus - 1) / cus;
+    q.rows_per_item = B * 4 >= cus ? T : (int)std::min<int64_t>(T, std::max<int64_t>(4 * kV3Waves, (want + kV3Waves - 1) / kV3Waves * kV3Waves));
+    q.nitems = (int64_t)((T + q.rows_per_item - 1) / q.rows_per_item) * B;
+    const size_t lds = (size_t)kPairSlots * sizeof(uint32_t) + (size_t)kV3Waves * ldq + kV3Waves * sizeof(double);
+    void (*kern)(V3Args) = k_comm_matrix_pairs<kV3Ahead>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     kern<<<(unsigned)std::min<int64_t>(cus, q.nitems), kV3Threads, lds, stream>>>(q);
     HIP_TRY(hipGetLastError());

@@ -324,6 +324,58 @@ def test_core_activity_and_comm_matrix_random(Q, T, C, B):
         assert (M[b] == M[b].T).all()
 
 
+@pytest.mark.parametrize("Q,T,C,B", [(1024, 40, 255, 420), (600, 130, 30, 130), (777, 33, 100, 500), (513, 70, 2, 240)])
+def test_comm_matrix_row_walk(Q, T, C, B):
+    """Batches on a circuit that visits most of every row take the communication counts from the pair counters of the
+    row walk: equal to the visit-by-visit kernel on every partition, to the oracle on a sample, error cases included."""
+    import torch
+    from oracle import placer_oracle as O
+    from quantum_simulator_amd import engine, layered_gate_arrays
+    from quantum_simulator_amd.timeslices import CircuitIR
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(Q + T)
+    q0, q1, _ = layered_gate_arrays(Q, T, 0.7, seed=Q + T)
+    keep = rng.random(len(q0)) >= 0.1
+    ir = CircuitIR.from_gate_tables(Q, q0[keep], q1[keep])
+    assert ir.nV >= 128 * ir.T and B * ir.T >= 16384
+    walk, byvisit, eng = engine.DeviceCircuit(ir, dev), engine.DeviceCircuit(ir, dev, visit_mask=False), engine.Engine(dev)
+    A = rng.integers(0, C, size=(B, ir.T, walk.ldq), dtype=np.uint8)
+    A[:, :, Q:] = rng.integers(0, 256, size=(B, ir.T, walk.ldq - Q), dtype=np.uint8)
+    stay = rng.random((B, ir.T, Q)) < 0.6
+    for t in range(1, ir.T):
+        A[:, t, :Q] = np.where(stay[:, t], A[:, t - 1, :Q], A[:, t, :Q])
+    vm = ir.visit_mask(walk.ldq)[:, :Q] != 0
+    for b in range(20):  # only the visited qubits are placed
+        A[b, :, :Q][~vm] = 0xFF
+    for b in range(20, 40):  # a visited qubit is absent somewhere, from the first slice on in half of them
+        v = ir.visit_records[int(rng.integers(0, ir.nV))]
+        A[b, v["t"], v["q"]] = 0xFF
+        if b >= 30:
+            A[b, :v["t"], v["q"]] = 0xFF
+    if C < 255:
+        for b in range(40, 50):  # a core that does not exist, under a visit or not
+            t, q = int(rng.integers(0, ir.T)), int(rng.integers(0, Q))
+            A[b, t, q] = int(rng.integers(C, 255))
+    Ad = torch.from_numpy(A).to(dev)
+    M, status = eng.comm_matrix(walk, Ad, C)
+    Mr, sr = eng.comm_matrix(byvisit, Ad, C)
+    M, status, Mr, sr = M.cpu().numpy(), status.cpu().numpy(), Mr.cpu().numpy(), sr.cpu().numpy()
+    assert (status == sr).all(), np.flatnonzero(status != sr)[:8]
+    assert status[20:40].any() and not status[:20].any()
+    ok = status == 0
+    assert (M[ok] == Mr[ok]).all()
+    for b in (0, 19, 20, 29, 30, 39, 41, 49, B - 1):
+        rows = [[None if c == 0xFF else int(c) for c in r[:Q]] for r in A[b]]
+        if 40 <= b < 50 and status[b] == 1:
+            continue  # a visited core that does not exist is reported even where the walk would never index with it
+        try:
+            want = O.comm_matrix(ir.slices, ir.gate_q, ir.gate_mr, rows, C)
+        except O.CostError:
+            assert status[b] == 1, b
+            continue
+        assert status[b] == 0 and M[b].tolist() == want, b
+
+
 def test_gtrhqa_device_placement_large_batch():
     """Large batches run on small workgroups, small batches on one 16-wave workgroup per instance: both
     must give the oracle's rows."""

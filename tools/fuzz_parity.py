@@ -124,9 +124,13 @@ def main():
         return [pick(2, 80), pick(81, 512), pick(513, 1024), pick(1025, 1600)][pick(0, 3)]
 
     def draw():
-        kind = pick(0, 12)
+        kind = pick(0, 13)
         if os.environ.get("QP_FUZZ_KIND"):  # one kind of case only
             kind = int(os.environ["QP_FUZZ_KIND"])
+        if kind == 13:  # communication counts from the pair counters of the row walk: whole partitions or chunks
+            B = pick(50, 63) if pick(0, 2) == 0 else pick(64, 500)
+            T = pick(16384 // B + 1, 16384 // B + 60)
+            return "comm_matrix_row_walk", TP.test_comm_matrix_row_walk, (pick(513, 1024), T, pick(2, 255), B)
         if kind == 12:  # gate-ordered cost as a row walk: whole partitions or chunks of slices, looked up or pair-counted
             if pick(0, 1):  # rows of at most 512 bytes: several partitions per wave step, from 64 MB on
                 Q = pick(8, 512)

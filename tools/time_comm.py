@@ -1,0 +1,44 @@
+"""Times the communication-count matrix of the gate-ordered walk on the benchmark circuit, from the pair counters of
+the row walk and visit by visit: time_comm.py [B]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from bench import make_partitions  # noqa: E402
+from quantum_simulator_amd import layered_gate_arrays  # noqa: E402
+from quantum_simulator_amd.engine import DeviceCircuit, Engine  # noqa: E402
+from quantum_simulator_amd.timeslices import CircuitIR  # noqa: E402
+
+
+def main():
+    dev = torch.device("cuda", 0)
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+    Q, T, C = 1024, 1000, 255
+    q0, q1, _ = layered_gate_arrays(Q, T, 0.5, seed=2025)
+    ir = CircuitIR.from_gate_tables(Q, q0, q1)
+    eng = Engine(dev)
+    forms = (("pair counters of the row walk", DeviceCircuit(ir, dev)), ("visit by visit", DeviceCircuit(ir, dev, visit_mask=False)))
+    A = make_partitions(torch, dev, B, ir.T, Q, forms[0][1].ldq, C, 8, 0.95, seed=777)
+    outs = []
+    for name, dc in forms:
+        for _ in range(2):
+            M, status = eng.comm_matrix(dc, A, C)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            M, status = eng.comm_matrix(dc, A, C)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 3
+        outs.append((M.cpu(), status.cpu()))
+        print(f"{name}: B={B} {ms:.3f} ms (zeroing the {B * C * C * 4 / 1e6:.0f} MB of matrices included)  "
+              f"{A.numel() / ms / 1e9:.3f} TB/s of rows  events in partition 0: {int(M[0].sum().item()) // 2}", flush=True)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), "forms disagree"
+
+
+if __name__ == "__main__":
+    main()
