@@ -91,6 +91,57 @@ __global__ __launch_bounds__(kThreads) void k_comm_matrix(const uint8_t* A, cons
     if (bad) status[b] = 1;
 }
 
+// The same with the matrix in LDS (up to 128 cores): grid = (chunks of visits, B); a workgroup walks its chunk of the
+// partition's visits, counts into its own copy and adds what is not zero to the caller's matrix at the end (stores it
+// when the partition is one chunk).  The global atomics of k_comm_matrix meet on a few hundred addresses per partition.
+__global__ __launch_bounds__(kThreads) void k_comm_matrix_lds(const uint8_t* A, const QpVisit* visits, int32_t nV, int32_t per_chunk,
+                                                              int64_t Tp, int32_t ldq, int32_t C, int32_t* out, int32_t* status) {
+    extern __shared__ int32_t lm[];
+    const int64_t b = blockIdx.y;
+    const int v0 = blockIdx.x * per_chunk, v1 = min(nV, v0 + per_chunk);
+    for (int k = threadIdx.x; k < C * C; k += kThreads) lm[k] = 0;
+    __syncthreads();
+    const uint8_t* base = A + (size_t)b * Tp * ldq;
+    bool bad = false;
+    for (int i = v0 + threadIdx.x; i < v1; i += kThreads) {
+        const QpVisit v = visits[i];
+        const uint32_t cur = base[(size_t)v.t * ldq + v.q];
+        const uint32_t oth = base[(size_t)v.t * ldq + (v.partner != 0xFFFFu ? v.partner : v.q)];
+        const uint32_t last = base[(size_t)(v.prev_t >= 0 ? v.prev_t : v.t) * ldq + v.q];
+        if (cur != QP_ABSENT && cur >= (uint32_t)C) {  // as in k_comm_matrix: reported, never used as an index
+            bad = true;
+            continue;
+        }
+        if (v.partner != 0xFFFFu) {
+            if (cur == QP_ABSENT || oth == QP_ABSENT || oth >= (uint32_t)C) {
+                bad = true;
+            } else if (cur != oth) {
+                atomicAdd(&lm[cur * C + oth], 1);
+                atomicAdd(&lm[oth * C + cur], 1);
+            }
+        }
+        if (v.prev_t >= 0 && last != QP_ABSENT && cur != last) {
+            if (cur == QP_ABSENT || last >= (uint32_t)C) {
+                bad = true;
+            } else {
+                atomicAdd(&lm[cur * C + last], 1);
+                atomicAdd(&lm[last * C + cur], 1);
+            }
+        }
+    }
+    if (bad) status[b] = 1;
+    __syncthreads();
+    int32_t* M = out + (size_t)b * C * C;
+    const bool only_writer = gridDim.x == 1;
+    for (int k = threadIdx.x; k < C * C; k += kThreads) {
+        const int32_t n = lm[k];
+        if (n) {
+            if (only_writer) M[k] = n;
+            else atomicAdd(&M[k], n);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int qp_core_activity(const QpCircuit* circ, const uint8_t* A, int64_t B, int32_t Tp, int32_t ldq, int32_t C,
@@ -129,6 +180,20 @@ extern "C" int qp_comm_matrix(const QpCircuit* circ, const uint8_t* A, int64_t B
     // large batches on a circuit that visits most of every row: the pair counters of the row walk are the matrix
     if (const int rc = qp::comm_matrix_pairs(circ, A, B, Tp, ldq, C, out, status, stream_); rc <= 0) return rc;
     if (!circ->visits) return qp::fail(QP_EINVAL, "qp_comm_matrix: circuit visit table missing");
+    if (C <= 128) {
+        // chunks of 4096 visits or more, whole partitions once those alone give every CU a few workgroups
+        const int cus = qp::device_cus();
+        const int64_t want_chunks = std::max<int64_t>(1, ((int64_t)cus * 4 + B - 1) / B);
+        const int64_t per = std::max<int64_t>(4096, (circ->nV + want_chunks - 1) / want_chunks);
+        const int32_t per_chunk = (int32_t)std::min<int64_t>(circ->nV, (per + kThreads - 1) / kThreads * kThreads);
+        const dim3 lgrid((unsigned)((circ->nV + per_chunk - 1) / per_chunk), (unsigned)B);
+        const size_t lds = (size_t)C * C * sizeof(int32_t);
+        if (lds > 48 * 1024)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_comm_matrix_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        k_comm_matrix_lds<<<lgrid, kThreads, lds, stream>>>(A, circ->visits, circ->nV, per_chunk, Tp, ldq, C, out, status);
+        HIP_TRY(hipGetLastError());
+        return QP_OK;
+    }
     const dim3 grid((unsigned)((circ->nV + kThreads - 1) / kThreads), (unsigned)B);
     k_comm_matrix<<<grid, kThreads, 0, stream>>>(A, circ->visits, circ->nV, Tp, ldq, C, out, status);
     HIP_TRY(hipGetLastError());

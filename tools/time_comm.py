@@ -1,5 +1,5 @@
 """Times the communication-count matrix of the gate-ordered walk on the benchmark circuit, from the pair counters of
-the row walk and visit by visit: time_comm.py [B]"""
+the row walk and visit by visit: time_comm.py [B [Q T C]]"""
 import os
 import sys
 
@@ -16,7 +16,7 @@ from quantum_simulator_amd.timeslices import CircuitIR  # noqa: E402
 def main():
     dev = torch.device("cuda", 0)
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-    Q, T, C = 1024, 1000, 255
+    Q, T, C = (int(x) for x in sys.argv[2:5]) if len(sys.argv) > 4 else (1024, 1000, 255)
     q0, q1, _ = layered_gate_arrays(Q, T, 0.5, seed=2025)
     ir = CircuitIR.from_gate_tables(Q, q0, q1)
     eng = Engine(dev)
