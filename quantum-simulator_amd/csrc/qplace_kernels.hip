@@ -3261,9 +3261,11 @@ extern "C" int qp_slice_cost_v2(const QpCircuit* circ, const QpDTable* dt, const
                           (vprev_ok ? (int64_t)B * T >= 65536 : B >= 1024);
     const int wcus = qp::device_cus();
     // rows of at most 512 bytes: the same walk with G partitions per wave step
-    const int32_t wlpr = ldq / 16, wG = wlpr > 0 && wlpr <= 32 ? kWave / wlpr : 0;
-    if (wG >= 2 && circ->visit_mask && circ->visit_mask_ldq == ldq && vprev_ok && circ->edges && circ->slice_edge_ptr &&
-        circ->nE > 0 && (int64_t)circ->nV * 8 >= (int64_t)T * ldq && B >= wG && (int64_t)B * T * ldq >= ((int64_t)1 << 26) &&
+    // (and longer rows on up to 16 cores, one partition per step: this kernel's table form has a copy of every entry
+    // per LDS bank; 2.07 -> 1.79 ms per 4 GB on a 16-bit table, 2.56 -> 1.89 ms on an fp64 one, against the two below)
+    const int32_t wlpr = ldq / 16, wG = wlpr > 0 && (wlpr <= 32 || (wlpr <= 64 && dt->C <= 16)) ? kWave / wlpr : 0;
+    if (wG >= 1 && circ->visit_mask && circ->visit_mask_ldq == ldq && vprev_ok && circ->edges && circ->slice_edge_ptr &&
+        circ->nE > 0 && (int64_t)circ->nV * 8 >= (int64_t)T * ldq && B >= wG && ((int64_t)B * T * ldq >= ((int64_t)1 << 26) || (ldq > 512 && (int64_t)B * T >= 65536)) &&
         (dt->kind == QP_DT_U16 || dt->C <= 127)) {
         V2WalkArgs w{};
         w.A = A;

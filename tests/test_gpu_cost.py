@@ -457,7 +457,9 @@ def test_cost_v2_random(gpu, Q, T, C, B, integer):
     # rows of at most 512 bytes: several partitions per wave step (16-bit tables; fp64 up to 127 cores)
     (63, 260, 64, 4100, 0.1, True), (63, 260, 64, 4100, 0.1, False), (200, 220, 255, 1500, 0.2, True),
     (512, 120, 30, 1100, 0.0, False), (17, 240, 9, 9001, 0.0, True), (100, 250, 16, 2500, 0.3, False),
-    (300, 30, 100, 7400, 0.1, True), (200, 220, 127, 1500, 0.2, False), (256, 100, 65, 2700, 0.0, False)])
+    (300, 30, 100, 7400, 0.1, True), (200, 220, 127, 1500, 0.2, False), (256, 100, 65, 2700, 0.0, False),
+    # the same kernel on longer rows and up to 16 cores, one partition per step
+    (1024, 70, 16, 1000, 0.1, True), (530, 140, 9, 500, 0.2, False), (1000, 66, 3, 1030, 0.0, True)])
 def test_cost_v2_row_walk(gpu, Q, T, C, B, drop, integer):
     """Batches on a circuit that visits most qubits in most slices are walked row by row (16-bit tables looked up,
     symmetric fp64 tables through core-pair counts; few partitions in chunks of slices): equal to the visit-by-visit
