@@ -11,7 +11,9 @@ qp_slice_cost_v3 through the C ABI, inputs resident in HBM.
     python bench.py [--gpus N] [--steps K] [--warmup W] [--weights uniform|integer] [--partitions B]
                     [--source gtrhqa|walk] [--single] [--table packed|table] [--no-cpu] [--no-qubo]
 
-For N > 1 launch with torch.distributed.run (one rank per GPU); ranks work on disjoint partitions with
+For N > 1 either launch it with torch.distributed.run (one rank per GPU) or run it plainly: without WORLD_SIZE in
+the environment it starts its N ranks itself (as children, before anything touches the GPU) and relays rank 0's
+line.  Ranks work on disjoint partitions with
 no collective in the timed region; the final mean/min reduction over ranks (one RCCL all-reduce of a
 few doubles) is done once after it and reported as ``reduce_ms``.
 
@@ -262,7 +264,8 @@ def bench_broken_links(torch, dev, S=1024):
     rng = np.random.default_rng(99)
     W = np.tile(np.asarray(ctx.arch.w, np.float64), (S, 1))
     W[rng.random(W.shape) < 0.1] = np.inf
-    threads = max(1, min(16, len(os.sched_getaffinity(0))))
+    from quantum_simulator_amd._lib import host_threads
+    threads = host_threads(16)
     t0 = time.perf_counter()
     tables = engine.apsp_batch(ctx.arch.C, ctx.arch.eu, ctx.arch.ev, W, threads=threads)
     t_apsp = time.perf_counter() - t0
@@ -298,6 +301,23 @@ def bench_broken_links(torch, dev, S=1024):
             "note": "cost launch: one workgroup per partition stages that partition's 32 KB table in LDS; bytes = rows + tables"}
 
 
+def launch_ranks(n):
+    """``python bench.py --gpus N`` without a launcher around it: this process starts N ranks of the same command
+    line under torch.distributed.run (one per GPU, rendezvous on 127.0.0.1 at a free port), hands their output
+    through and exits with their code.  Nothing here touches the GPU (no torch import): the ranks are children,
+    not replacements of this process."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -325,6 +345,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -333,7 +356,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus differ")
     # one rank per GPU.  For a rehearsal of the multi-rank control flow on a box with fewer GPUs than ranks,
     # QP_BENCH_BACKEND=gloo lets ranks share a device (RCCL refuses two ranks on one GPU; gloo does not care)
     backend = os.environ.get("QP_BENCH_BACKEND", "nccl")
@@ -349,8 +372,22 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    # what ran where, for whoever reads the line: the collective backend, its world size and every rank's device
+    props = torch.cuda.get_device_properties(dev)
+    mine = {"rank": rank, "device": f"cuda:{dev.index}", "name": props.name,
+            "pci_bus_id": getattr(props, "pci_bus_id", None), "uuid": str(getattr(props, "uuid", "")) or None}
+    if dist.is_initialized():
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        distributed = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks": gathered}
+    else:
+        distributed = {"backend": None, "world_size": 1, "ranks": [mine]}
+
     from quantum_simulator_amd import layered_gate_arrays
+    from quantum_simulator_amd._lib import host_threads
     from quantum_simulator_amd.engine import DeviceCircuit, DistanceTable, Engine, apsp, QP_DT_U16
+    distributed["host_threads_per_rank"] = {"share": host_threads(1 << 20), "polling_lanes": host_threads(8, polling=True),
+                                            "local_world_size": int(os.environ.get("LOCAL_WORLD_SIZE", "1"))}
     from quantum_simulator_amd.multicore import graph_tables, multicore
     from quantum_simulator_amd.timeslices import CircuitIR
 
@@ -587,6 +624,7 @@ def main():
                        "seeds": {"circuit": circ_seed, "weights": weight_seed, "partitions": "777+rank"},
                        "table": primary["table"]},
             "roofline": primary["roofline"], "mean_cost": primary["mean_cost"], "min_cost": primary["min_cost"],
+            "distributed": distributed,
             "reduce_ms": primary["reduce_ms"], "gtrhqa_place": place, "cost_matrix": cm, "core_activity": activity, "gate_ordered_cost": gate_ordered, "qubo": qubo,
             "shipped_circuits": shipped, "shipped_circuits_cost_at_scale": shipped_cost, "broken_links": broken,
         }

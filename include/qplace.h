@@ -35,6 +35,7 @@ extern "C" {
 #define QP_EHIP (-2)     /* a HIP runtime call failed */
 #define QP_ENOSPC (-3)   /* caller-provided buffer or workspace too small */
 #define QP_EINFEASIBLE (-4) /* assignment problem has no finite solution */
+#define QP_ENOMEM (-5)   /* a host allocation (or a host worker thread's) failed */
 
 #define QP_ABSENT 0xFF
 
@@ -129,6 +130,16 @@ int qp_version(void);
 const char* qp_last_error(void);
 
 /* ---------------------------------------------------------------- host-side pieces */
+
+/* Host threads the calling process should use for one call: min(limit, budget), at least 1.  The budget is the
+ * number of CPUs the process may run on (its affinity mask) divided by the number of ranks that share the
+ * node (LOCAL_WORLD_SIZE in the environment, as torch.distributed.run exports it; 1 when absent), unless
+ * qp_set_host_threads gave a positive number (0 restores the default).  Every call below that chooses its own
+ * thread count (qp_place_sparse) goes through it, and the Python side asks it for the default of every
+ * `threads` / `lanes` argument, so that N ranks on one node do not start N times the node's cores in threads.
+ * No reference counterpart: the reference is one Python thread (main.py:85-105 runs its repeats one by one). */
+int32_t qp_host_threads(int32_t limit);
+int qp_set_host_threads(int32_t n);
 
 /* All-pairs core distances, host.  Row i is a Dijkstra from source i that accumulates dist[u] + w
  * outwards; unreachable pairs fall back to hop counts, then +inf; the diagonal is 0.

@@ -65,6 +65,8 @@ class QplaceError(RuntimeError):
 EXPORTS = {
     "qp_version": (C.c_int, []),
     "qp_last_error": (C.c_char_p, []),
+    "qp_host_threads": (C.c_int32, [C.c_int32]),
+    "qp_set_host_threads": (C.c_int, [C.c_int32]),
     "qp_apsp_f64": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "qp_hops_f64": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "qp_lsap_f64": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -158,6 +160,16 @@ def lib():
             fn.argtypes = args
         _lib = L
     return _lib
+
+
+def host_threads(limit, polling=False):
+    """Default for every ``threads`` / ``lanes`` argument: min(limit, this process's share of the node's CPUs) --
+    the CPUs it may run on divided by the ranks on the node (LOCAL_WORLD_SIZE), see qp_host_threads.  Lanes that
+    spin on a stream (``polling``) take half of the share, so that the solver threads beside them get a core too."""
+    share = int(lib().qp_host_threads(1 << 20))
+    if polling:
+        share = max(1, share // 2)
+    return max(1, min(int(limit), share))
 
 
 def check(rc):

@@ -11,6 +11,7 @@
 #include <functional>
 #include <limits>
 #include <queue>
+#include <sched.h>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -28,6 +29,37 @@ int fail(int code, const char* fmt, ...) {
 }
 
 }  // namespace qp
+
+namespace qp {
+
+static std::atomic<int32_t> g_thread_budget{0};  // 0: derive from the affinity mask and LOCAL_WORLD_SIZE
+
+int32_t host_threads(int32_t limit) {
+    int32_t budget = g_thread_budget.load();
+    if (budget <= 0) {
+        cpu_set_t set;
+        long cpus = 0;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) cpus = CPU_COUNT(&set);
+        if (cpus <= 0) cpus = (long)std::max(1u, std::thread::hardware_concurrency());
+        long ranks = 1;
+        if (const char* env = std::getenv("LOCAL_WORLD_SIZE")) {
+            char* end = nullptr;
+            const long v = std::strtol(env, &end, 10);
+            if (end != env && v > 0) ranks = v;
+        }
+        budget = (int32_t)std::max(1L, std::min(cpus / ranks, 1L << 20));
+    }
+    return std::max(1, std::min(limit, budget));
+}
+
+}  // namespace qp
+
+extern "C" int32_t qp_host_threads(int32_t limit) { return qp::host_threads(limit); }
+extern "C" int qp_set_host_threads(int32_t n) {
+    if (n < 0) return qp::fail(QP_EINVAL, "qp_set_host_threads: n must be >= 0");
+    qp::g_thread_budget.store(n);
+    return QP_OK;
+}
 
 extern "C" int qp_version(void) { return QP_VERSION; }
 extern "C" const char* qp_last_error(void) { return qp::g_err; }
@@ -87,7 +119,7 @@ void bfs_hops(const Adj& a, int32_t C, int32_t src, std::vector<int32_t>& hop) {
 }  // namespace
 
 extern "C" int qp_apsp_f64(int32_t C, int32_t nE, const int32_t* eu, const int32_t* ev, const double* w,
-                           double* D) {
+                           double* D) try {
     if (C <= 0 || nE < 0 || !D || (nE > 0 && (!eu || !ev || !w))) return qp::fail(QP_EINVAL, "qp_apsp_f64: bad argument");
     Adj a;
     if (int rc = build_adj(C, nE, eu, ev, w, a)) return rc;
@@ -139,10 +171,14 @@ extern "C" int qp_apsp_f64(int32_t C, int32_t nE, const int32_t* eu, const int32
         }
     }
     return QP_OK;
+} catch (const std::exception& e) {
+    return qp::fail(QP_ENOMEM, "qp_apsp_f64: %s", e.what());
+} catch (...) {
+    return qp::fail(QP_ENOMEM, "qp_apsp_f64: unknown exception");
 }
 
 extern "C" int qp_apsp_f64_batch(int32_t C, int32_t nE, const int32_t* eu, const int32_t* ev, const double* w,
-                                 int32_t S, double* D, int32_t threads) {
+                                 int32_t S, double* D, int32_t threads) try {
     if (S < 0 || C <= 0 || nE < 0 || (S > 0 && !D) || (S > 0 && nE > 0 && (!eu || !ev || !w)))
         return qp::fail(QP_EINVAL, "qp_apsp_f64_batch: bad argument");
     for (int32_t e = 0; e < nE; ++e)
@@ -156,19 +192,17 @@ extern "C" int qp_apsp_f64_batch(int32_t C, int32_t nE, const int32_t* eu, const
             if (rc != QP_OK) rcs[tid] = rc;
         }
     };
-    if (threads == 1) {
-        work(0);
-    } else {
-        std::vector<std::thread> pool;
-        for (int32_t tdx = 0; tdx < threads; ++tdx) pool.emplace_back(work, tdx);
-        for (auto& th : pool) th.join();
-    }
+    if (int rc = qp::run_workers(threads, work)) return rc;
     for (int rc : rcs)
         if (rc != QP_OK) return qp::fail(rc, "qp_apsp_f64_batch: a graph of the batch was rejected");
     return QP_OK;
+} catch (const std::exception& e) {
+    return qp::fail(QP_ENOMEM, "qp_apsp_f64_batch: %s", e.what());
+} catch (...) {
+    return qp::fail(QP_ENOMEM, "qp_apsp_f64_batch: unknown exception");
 }
 
-extern "C" int qp_hops_f64(int32_t C, int32_t nE, const int32_t* eu, const int32_t* ev, double* H) {
+extern "C" int qp_hops_f64(int32_t C, int32_t nE, const int32_t* eu, const int32_t* ev, double* H) try {
     if (C <= 0 || nE < 0 || !H || (nE > 0 && (!eu || !ev))) return qp::fail(QP_EINVAL, "qp_hops_f64: bad argument");
     Adj a;
     if (int rc = build_adj(C, nE, eu, ev, nullptr, a)) return rc;
@@ -179,6 +213,10 @@ extern "C" int qp_hops_f64(int32_t C, int32_t nE, const int32_t* eu, const int32
             H[(size_t)s * C + j] = hop[j] < 0 ? std::numeric_limits<double>::infinity() : (double)hop[j];
     }
     return QP_OK;
+} catch (const std::exception& e) {
+    return qp::fail(QP_ENOMEM, "qp_hops_f64: %s", e.what());
+} catch (...) {
+    return qp::fail(QP_ENOMEM, "qp_hops_f64: unknown exception");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -299,7 +337,7 @@ int qp::lsap(int32_t nr, int32_t nc, const double* cost, int32_t ld, int32_t* ro
     return lsap_solve(nr, nc, cost, ld, row_out, col_out, work->s);
 }
 
-extern "C" int qp_lsap_f64(int32_t nr, int32_t nc, const double* cost, int32_t* row_out, int32_t* col_out) {
+extern "C" int qp_lsap_f64(int32_t nr, int32_t nc, const double* cost, int32_t* row_out, int32_t* col_out) try {
     if (nr < 0 || nc < 0 || ((nr > 0 && nc > 0) && (!cost || !row_out || !col_out)))
         return qp::fail(QP_EINVAL, "qp_lsap_f64: bad argument");
     LsapScratch s;
@@ -307,11 +345,15 @@ extern "C" int qp_lsap_f64(int32_t nr, int32_t nc, const double* cost, int32_t* 
     if (rc == QP_EINVAL) return qp::fail(rc, "qp_lsap_f64: matrix contains invalid numeric entries");
     if (rc == QP_EINFEASIBLE) return qp::fail(rc, "qp_lsap_f64: cost matrix is infeasible");
     return rc;
+} catch (const std::exception& e) {
+    return qp::fail(QP_ENOMEM, "qp_lsap_f64: %s", e.what());
+} catch (...) {
+    return qp::fail(QP_ENOMEM, "qp_lsap_f64: unknown exception");
 }
 
 extern "C" int qp_lsap_f64_batch(int32_t n, const int32_t* nr, const int32_t* nc, const double* cost,
                                  int64_t stride, int32_t ld, int32_t* row_out, int32_t* col_out,
-                                 int32_t out_stride, int32_t* status, int32_t threads) {
+                                 int32_t out_stride, int32_t* status, int32_t threads) try {
     if (n < 0 || (n > 0 && (!nr || !nc || !cost || !row_out || !col_out || !status)))
         return qp::fail(QP_EINVAL, "qp_lsap_f64_batch: bad argument");
     for (int32_t k = 0; k < n; ++k)
@@ -324,14 +366,11 @@ extern "C" int qp_lsap_f64_batch(int32_t n, const int32_t* nr, const int32_t* nc
             status[k] = lsap_solve(nr[k], nc[k], cost + (size_t)k * stride, ld, row_out + (size_t)k * out_stride,
                                    col_out + (size_t)k * out_stride, s);
     };
-    if (threads == 1) {
-        work(0);
-    } else {
-        std::vector<std::thread> pool;
-        for (int32_t tdx = 0; tdx < threads; ++tdx) pool.emplace_back(work, tdx);
-        for (auto& th : pool) th.join();
-    }
-    return QP_OK;
+    return qp::run_workers(threads, work);
+} catch (const std::exception& e) {
+    return qp::fail(QP_ENOMEM, "qp_lsap_f64_batch: %s", e.what());
+} catch (...) {
+    return qp::fail(QP_ENOMEM, "qp_lsap_f64_batch: unknown exception");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -339,7 +378,7 @@ extern "C" int qp_lsap_f64_batch(int32_t n, const int32_t* nr, const int32_t* nc
 // ------------------------------------------------------------------------------------------------
 
 extern "C" int qp_dtable_pack(const double* D, int32_t C, void* staging, size_t staging_bytes, int32_t* kind_out,
-                              size_t* bytes_out) {
+                              size_t* bytes_out) try {
     if (!D || C <= 0 || C > 256 || !staging || !kind_out || !bytes_out)
         return qp::fail(QP_EINVAL, "qp_dtable_pack: bad argument (C must be 1..256)");
     const size_t n = (size_t)C * C;
@@ -363,10 +402,14 @@ extern "C" int qp_dtable_pack(const double* D, int32_t C, void* staging, size_t 
         *bytes_out = n * 8;
     }
     return QP_OK;
+} catch (const std::exception& e) {
+    return qp::fail(QP_ENOMEM, "qp_dtable_pack: %s", e.what());
+} catch (...) {
+    return qp::fail(QP_ENOMEM, "qp_dtable_pack: unknown exception");
 }
 
 extern "C" int qp_make_space(uint8_t* a, int64_t* occ, const int64_t* rows, int64_t n_rows, int32_t Q, int32_t lda,
-                             int32_t C, int32_t cap, const double* D) {
+                             int32_t C, int32_t cap, const double* D) try {
     if (!a || !occ || (n_rows > 0 && !rows) || !D || n_rows < 0 || Q <= 0 || lda < Q || C <= 0 || C > 256)
         return qp::fail(QP_EINVAL, "qp_make_space: bad arguments");
     for (int64_t k = 0; k < n_rows; ++k) {
@@ -374,6 +417,10 @@ extern "C" int qp_make_space(uint8_t* a, int64_t* occ, const int64_t* rows, int6
         qp::make_space_row(a + (size_t)rows[k] * lda, occ + (size_t)rows[k] * C, Q, C, cap, D);
     }
     return QP_OK;
+} catch (const std::exception& e) {
+    return qp::fail(QP_ENOMEM, "qp_make_space: %s", e.what());
+} catch (...) {
+    return qp::fail(QP_ENOMEM, "qp_make_space: unknown exception");
 }
 
 void qp::make_space_row(uint8_t* ar, int64_t* oc, int32_t Q, int32_t C, int32_t cap, const double* D) {
@@ -402,7 +449,7 @@ void qp::make_space_row(uint8_t* ar, int64_t* oc, int32_t Q, int32_t C, int32_t 
     }
 }
 
-extern "C" int qp_dtable_symmetric(const double* D, int32_t C, double rel_tol) {
+extern "C" int qp_dtable_symmetric(const double* D, int32_t C, double rel_tol) try {
     if (!D || C <= 0 || !(rel_tol >= 0.0)) return qp::fail(QP_EINVAL, "qp_dtable_symmetric: bad arguments");
     for (int32_t a = 0; a < C; ++a) {
         for (int32_t b = a + 1; b < C; ++b) {
@@ -416,9 +463,13 @@ extern "C" int qp_dtable_symmetric(const double* D, int32_t C, double rel_tol) {
         }
     }
     return 1;
+} catch (const std::exception& e) {
+    return qp::fail(QP_ENOMEM, "qp_dtable_symmetric: %s", e.what());
+} catch (...) {
+    return qp::fail(QP_ENOMEM, "qp_dtable_symmetric: unknown exception");
 }
 
-extern "C" int qp_dtable_grid_metric(const double* D, int32_t C, QpGridMetric* out) {
+extern "C" int qp_dtable_grid_metric(const double* D, int32_t C, QpGridMetric* out) try {
     if (!D || !out || C <= 0 || C > 256) return qp::fail(QP_EINVAL, "qp_dtable_grid_metric: bad argument");
     *out = QpGridMetric{};
     const size_t n = (size_t)C * C;
@@ -463,6 +514,10 @@ extern "C" int qp_dtable_grid_metric(const double* D, int32_t C, QpGridMetric* o
         }
     }
     return QP_OK;
+} catch (const std::exception& e) {
+    return qp::fail(QP_ENOMEM, "qp_dtable_grid_metric: %s", e.what());
+} catch (...) {
+    return qp::fail(QP_ENOMEM, "qp_dtable_grid_metric: unknown exception");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -488,7 +543,7 @@ inline bool second_first(int64_t a, int64_t b) {
 }  // namespace
 
 extern "C" int qp_timeslices(int32_t n_gates, const int32_t* gq0, const int32_t* gq1, int32_t Q, int32_t* order_out,
-                             int32_t* slice_ptr_out, int32_t* T_out) {
+                             int32_t* slice_ptr_out, int32_t* T_out) try {
     if (n_gates < 0 || Q <= 0 || !T_out || (n_gates > 0 && (!gq0 || !gq1 || !order_out || !slice_ptr_out)))
         return qp::fail(QP_EINVAL, "qp_timeslices: bad argument");
     std::vector<int32_t> last(Q, -1);
@@ -542,6 +597,10 @@ extern "C" int qp_timeslices(int32_t n_gates, const int32_t* gq0, const int32_t*
     }
     *T_out = T;
     return QP_OK;
+} catch (const std::exception& e) {
+    return qp::fail(QP_ENOMEM, "qp_timeslices: %s", e.what());
+} catch (...) {
+    return qp::fail(QP_ENOMEM, "qp_timeslices: unknown exception");
 }
 
 namespace {
@@ -593,7 +652,7 @@ int32_t spread_over_banks(const std::vector<std::pair<uint16_t, uint16_t>>& pair
 }  // namespace
 
 extern "C" int qp_schedule_gates(int32_t T, const int32_t* slice_edge_ptr, const uint16_t* eu, const uint16_t* ev,
-                                 int32_t* sched_ptr_out, uint32_t* sched_out, int64_t sched_capacity) {
+                                 int32_t* sched_ptr_out, uint32_t* sched_out, int64_t sched_capacity) try {
     if (T < 0 || !slice_edge_ptr || !sched_ptr_out || !sched_out || (slice_edge_ptr[T] > 0 && (!eu || !ev)))
         return qp::fail(QP_EINVAL, "qp_schedule_gates: bad argument");
     int64_t need = QP_SCHED_TAIL;
@@ -613,6 +672,10 @@ extern "C" int qp_schedule_gates(int32_t T, const int32_t* slice_edge_ptr, const
         spread_over_banks(pairs, sched_out + w);
     }
     return QP_OK;
+} catch (const std::exception& e) {
+    return qp::fail(QP_ENOMEM, "qp_schedule_gates: %s", e.what());
+} catch (...) {
+    return qp::fail(QP_ENOMEM, "qp_schedule_gates: unknown exception");
 }
 
 extern "C" int32_t qp_group_rows(int32_t ldq) {
@@ -621,7 +684,7 @@ extern "C" int32_t qp_group_rows(int32_t ldq) {
 }
 
 extern "C" int qp_schedule_gate_groups(int32_t T, const int32_t* slice_edge_ptr, const uint16_t* eu, const uint16_t* ev,
-                                       int32_t ldq, int32_t* group_ptr_out, uint32_t* sched_out, int64_t sched_capacity) {
+                                       int32_t ldq, int32_t* group_ptr_out, uint32_t* sched_out, int64_t sched_capacity) try {
     const int32_t G = qp_group_rows(ldq);
     if (T < 0 || G == 0 || !slice_edge_ptr || !group_ptr_out || !sched_out || (slice_edge_ptr[T] > 0 && (!eu || !ev)))
         return qp::fail(QP_EINVAL, "qp_schedule_gate_groups: bad argument (rows of 16 to 512 bytes, a multiple of 16)");
@@ -652,6 +715,10 @@ extern "C" int qp_schedule_gate_groups(int32_t T, const int32_t* slice_edge_ptr,
         spread_over_banks(pairs, sched_out + w);
     }
     return QP_OK;
+} catch (const std::exception& e) {
+    return qp::fail(QP_ENOMEM, "qp_schedule_gate_groups: %s", e.what());
+} catch (...) {
+    return qp::fail(QP_ENOMEM, "qp_schedule_gate_groups: unknown exception");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -686,7 +753,7 @@ inline bool is_keyword(const char* s, int64_t len) {
 
 extern "C" int qp_qasm_scan(const char* text, int64_t n, int64_t start, int32_t n_regs, const char* reg_names,
                             const int32_t* reg_size, const int32_t* reg_base, int64_t cap, uint64_t* name_hash,
-                            int32_t* name_pos, int32_t* param_pos, int32_t* qidx, int64_t* n_out, int64_t* stop_out) {
+                            int32_t* name_pos, int32_t* param_pos, int32_t* qidx, int64_t* n_out, int64_t* stop_out) try {
     if (!text || n < 0 || start < 0 || start > n || cap < 0 || !n_out || !stop_out || n > 0x7FFFFFFF ||
         (cap > 0 && (!name_hash || !name_pos || !param_pos || !qidx)) || (n_regs > 0 && (!reg_names || !reg_size || !reg_base)))
         return qp::fail(QP_EINVAL, "qp_qasm_scan: bad argument");
@@ -794,6 +861,10 @@ extern "C" int qp_qasm_scan(const char* text, int64_t n, int64_t start, int32_t 
     *n_out = count;
     *stop_out = i;
     return QP_OK;
+} catch (const std::exception& e) {
+    return qp::fail(QP_ENOMEM, "qp_qasm_scan: %s", e.what());
+} catch (...) {
+    return qp::fail(QP_ENOMEM, "qp_qasm_scan: unknown exception");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -848,7 +919,7 @@ struct PyRandom {
 extern "C" int qp_place_sparse(int32_t which, int32_t T, int32_t Q, int32_t ldq, int32_t C, int32_t cap,
                                const int32_t* member_ptr, const uint16_t* members, const int32_t* cmd_ptr,
                                const int32_t* cmd_q0, const int32_t* cmd_q1, const int32_t* nb_ptr, const int32_t* nb,
-                               const double* D, uint32_t* mt_states, int32_t n_states, int32_t n_rep, uint8_t* A_out) {
+                               const double* D, uint32_t* mt_states, int32_t n_states, int32_t n_rep, uint8_t* A_out) try {
     if (which != QP_PLACE_RANDOM && which != QP_PLACE_BFS) return qp::fail(QP_EINVAL, "qp_place_sparse: unknown placer %d", which);
     if (T < 0 || Q <= 0 || ldq < Q || C <= 0 || C > 255 || cap < 0 || n_rep < 0 || !member_ptr || !mt_states ||
         (n_states != 1 && n_states != n_rep) || (n_rep > 0 && !A_out) || (member_ptr[T] > 0 && !members))
@@ -962,16 +1033,12 @@ extern "C" int qp_place_sparse(int32_t which, int32_t T, int32_t Q, int32_t ldq,
         }
     }
     };
-    const int32_t workers = (n_states == n_rep && n_rep > 1)
-                                ? (int32_t)std::min<int64_t>({(int64_t)n_rep, 16, (int64_t)std::max(1u, std::thread::hardware_concurrency())})
-                                : 1;
-    if (workers <= 1) {
-        run_reps(0, n_rep);
-    } else {
-        std::vector<std::thread> pool;
-        for (int32_t w = 0; w < workers; ++w)
-            pool.emplace_back(run_reps, (int32_t)((int64_t)n_rep * w / workers), (int32_t)((int64_t)n_rep * (w + 1) / workers));
-        for (auto& th : pool) th.join();
-    }
-    return QP_OK;
+    const int32_t workers = (n_states == n_rep && n_rep > 1) ? std::min(n_rep, qp::host_threads(16)) : 1;
+    return qp::run_workers(workers, [&](int32_t w) {
+        run_reps((int32_t)((int64_t)n_rep * w / workers), (int32_t)((int64_t)n_rep * (w + 1) / workers));
+    });
+} catch (const std::exception& e) {
+    return qp::fail(QP_ENOMEM, "qp_place_sparse: %s", e.what());
+} catch (...) {
+    return qp::fail(QP_ENOMEM, "qp_place_sparse: unknown exception");
 }

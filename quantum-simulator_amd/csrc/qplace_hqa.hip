@@ -210,7 +210,7 @@ extern "C" size_t qp_hqa_place_pinned_bytes(int32_t ldq, int32_t C, int32_t max_
 extern "C" int qp_hqa_place_batch_multi(int32_t kind, const QpCircuit* circ, const double* tables, int32_t S, int32_t C,
                                         const int32_t* tab_index, const int32_t* slice_edge_ptr, const QpEdge* edges,
                                         const double* D, int32_t cap, const uint8_t* initial, int64_t B, uint8_t* rows_out,
-                                        void* pinned, size_t pinned_bytes, int32_t lanes, void* const* streams) {
+                                        void* pinned, size_t pinned_bytes, int32_t lanes, void* const* streams) try {
     const char* fn = "qp_hqa_place_batch";
     if (kind != QP_CM_HQA && kind != QP_CM_TRHQA) return qp::fail(QP_EINVAL, "%s: kind must be QP_CM_HQA or QP_CM_TRHQA", fn);
     if (!circ || !tables || !slice_edge_ptr || !D || !initial || !rows_out || !pinned || !streams)
@@ -270,16 +270,16 @@ extern "C" int qp_hqa_place_batch_multi(int32_t kind, const QpCircuit* circ, con
         ln[l].slab = slab;
         slab += (size_t)(ln[l].b1 - ln[l].b0) * per + 128;
     }
-    if (lanes == 1) {
-        run_lane(bx, ln[0]);
-    } else {
-        std::vector<std::thread> pool;
-        for (int32_t l = 0; l < lanes; ++l) pool.emplace_back(run_lane, std::cref(bx), std::ref(ln[l]));
-        for (auto& th : pool) th.join();
-    }
+    // a lane whose thread cannot be started runs on this thread after the others; a lane that throws (its
+    // scratch vectors) fails the call with QP_ENOMEM
+    if (int rc = qp::run_workers(lanes, [&](int32_t l) { run_lane(bx, ln[l]); })) return rc;
     for (int32_t l = 0; l < lanes; ++l)
         if (ln[l].rc != QP_OK) return qp::fail(ln[l].rc, "%s", ln[l].msg);
     return QP_OK;
+} catch (const std::exception& e) {
+    return qp::fail(QP_ENOMEM, "qp_hqa_place_batch: %s", e.what());
+} catch (...) {
+    return qp::fail(QP_ENOMEM, "qp_hqa_place_batch: unknown exception");
 }
 
 extern "C" int qp_hqa_place_batch(int32_t kind, const QpCircuit* circ, const QpDTable* dt, const int32_t* slice_edge_ptr,

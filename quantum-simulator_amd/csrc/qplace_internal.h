@@ -2,9 +2,58 @@
 #pragma once
 #include "../../include/qplace.h"
 
+#include <atomic>
+#include <exception>
+#include <new>
+#include <thread>
+#include <vector>
+
 namespace qp {
 // Records a printf-style message for qp_last_error() and returns `code`.
 int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+
+// fn(0) .. fn(n - 1), each on a host thread of its own (fn(0) on the caller's).  Nothing escapes: a worker
+// that cannot be started (thread limit of the process) is run on the calling thread after the others, and an
+// exception out of fn (a failed allocation in its own scratch vectors) ends that worker only and turns into
+// QP_ENOMEM for the call.  Returns QP_OK or QP_ENOMEM (message set).
+template <class F>
+int run_workers(int32_t n, F&& fn) {
+    std::atomic<int> bad{0};
+    auto guarded = [&](int32_t w) {
+        try {
+            fn(w);
+        } catch (const std::bad_alloc&) {
+            bad.store(1);
+        } catch (...) {
+            bad.store(2);
+        }
+    };
+    std::vector<std::thread> pool;
+    std::vector<int32_t> here;  // workers that run on the calling thread
+    try {
+        pool.reserve(n > 1 ? (size_t)(n - 1) : 0);
+        here.reserve(n > 0 ? (size_t)n : 0);
+    } catch (...) {
+        for (int32_t w = 0; w < n; ++w) guarded(w);
+        pool.clear();
+        return bad.load() ? fail(QP_ENOMEM, "a host worker ran out of memory or threw") : QP_OK;
+    }
+    here.push_back(0);
+    for (int32_t w = 1; w < n; ++w) {
+        try {
+            pool.emplace_back(guarded, w);
+        } catch (...) {
+            here.push_back(w);
+        }
+    }
+    for (int32_t w : here)
+        if (w < n) guarded(w);
+    for (auto& th : pool) th.join();
+    return bad.load() ? fail(QP_ENOMEM, "a host worker ran out of memory or threw") : QP_OK;
+}
+
+// Host threads a call of this process may start: min(limit, budget), at least 1 (see qp_host_threads).
+int32_t host_threads(int32_t limit);
 
 // Compute units of the current device (256 when the runtime cannot say).  Device translation units only.
 int device_cus();

@@ -52,8 +52,11 @@ def apsp(C_: int, eu, ev, w) -> np.ndarray:
     return D
 
 
-def apsp_batch(C_: int, eu, ev, W, threads: int = 8) -> np.ndarray:
-    """Distance matrices [S, C, C] of S networks that share their links and differ in the weights W [S, E]."""
+def apsp_batch(C_: int, eu, ev, W, threads=None) -> np.ndarray:
+    """Distance matrices [S, C, C] of S networks that share their links and differ in the weights W [S, E].
+    ``threads`` defaults to this process's share of the node's CPUs, at most 16 (``_lib.host_threads``)."""
+    if threads is None:
+        threads = _lib.host_threads(16)
     eu = np.ascontiguousarray(eu, np.int32)
     ev = np.ascontiguousarray(ev, np.int32)
     W = np.ascontiguousarray(W, np.float64)
@@ -84,8 +87,11 @@ def lsap(cost: np.ndarray):
     raise ValueError(lib().qp_last_error().decode())
 
 
-def lsap_batch(costs: np.ndarray, nr: np.ndarray, nc: np.ndarray, threads: int = 8):
-    """costs [n, R, L] (problem k uses the top-left nr[k] x nc[k]); returns rows, cols [n, min(R, L)], status."""
+def lsap_batch(costs: np.ndarray, nr: np.ndarray, nc: np.ndarray, threads=None):
+    """costs [n, R, L] (problem k uses the top-left nr[k] x nc[k]); returns rows, cols [n, min(R, L)], status.
+    ``threads`` defaults to this process's share of the node's CPUs, at most 8."""
+    if threads is None:
+        threads = _lib.host_threads(8)
     costs = np.ascontiguousarray(costs, np.float64)
     n, R, L = costs.shape
     nr = np.ascontiguousarray(nr, np.int32)
@@ -95,7 +101,7 @@ def lsap_batch(costs: np.ndarray, nr: np.ndarray, nc: np.ndarray, threads: int =
     cols = np.full((n, k), -1, np.int32)
     status = np.zeros(n, np.int32)
     check(lib().qp_lsap_f64_batch(n, ptr(nr), ptr(nc), ptr(costs), R * L, L, ptr(rows), ptr(cols), k, ptr(status),
-                                  threads))
+                                  int(threads)))
     return rows, cols, status
 
 

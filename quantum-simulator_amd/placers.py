@@ -10,7 +10,6 @@ Nothing here computes a cost on the CPU in Python.
 """
 from __future__ import annotations
 
-import os
 import random
 from bisect import insort
 from collections import deque
@@ -18,7 +17,7 @@ from collections import deque
 import numpy as np
 
 from . import engine as E
-from ._lib import QP_ABSENT, QP_PLACE_BFS, QP_PLACE_RANDOM, QP_CM_GTRHQA, QP_CM_HQA, QP_CM_TRHQA, QP_V1, QP_V2, QP_V4, check, lib, ptr
+from ._lib import QP_ABSENT, QP_PLACE_BFS, QP_PLACE_RANDOM, QP_CM_GTRHQA, QP_CM_HQA, QP_CM_TRHQA, QP_V1, QP_V2, QP_V4, check, host_threads, lib, ptr
 from .multicore import graph_tables
 from .timeslices import CircuitIR, circuit_ir
 
@@ -366,8 +365,8 @@ class _HqaFamily(BasePlacer):
     # -- many instances at once ----------------------------------------------------------------------
     def place_batch(self, circuit, multicore_arch, initial=None, B=None, threads=None, tables=None, tab_index=None):
         """B independent placements of one circuit on one architecture through qp_hqa_place_batch: the whole
-        per-slice loop is native; the batch is split over ``threads`` host threads (default: half the CPUs this
-        process may use, at most 8), each driving its instances on its own stream (cost matrices on the
+        per-slice loop is native; the batch is split over ``threads`` host threads (default: half of this process's
+        share of the node's CPUs -- its affinity mask divided by the ranks on the node -- at most 8), each driving its instances on its own stream (cost matrices on the
         device, assignment solves on the host).  ``initial`` is uint8 [B, Q] (row 0 of each instance; default:
         B copies of the block assignment, i.e. B identical repeats as main.py:88-92 runs them).  Returns uint8
         [B, T, Q]; instance b equals what ``place_per_timeslice`` gives when started from ``initial[b]``.
@@ -388,10 +387,10 @@ class _HqaFamily(BasePlacer):
         B = initial.shape[0]
         out = np.empty((B, self._rows_out(T), Q), np.uint8)
         if threads is None:
-            # half the CPUs this process may use, at most 8: every lane polls its stream, and more lanes than
+            # half of this rank's CPUs, at most 8: every lane polls its stream, and more lanes than
             # hardware queues plus solver threads only contend (64 x qft_n63 on the 8x8 torus: 12.6 ms on one
             # lane, 8.2 ms on 8, 11.6 ms on 16)
-            threads = max(1, min(8, len(os.sched_getaffinity(0)) // 2))
+            threads = host_threads(8, polling=True)
         lanes = max(1, min(int(threads), B))
         sep = np.ascontiguousarray(ir.slice_edge_ptr, np.int32)
         most = int(np.diff(sep).max()) if T else 0

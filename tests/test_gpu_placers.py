@@ -732,3 +732,30 @@ def test_rccl_all_reduce_of_the_result_table(tmp_path):
     out = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
                          timeout=280)
     assert out.returncode == 0 and "RCCL ok" in out.stdout, out.stdout
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_without_a_launcher():
+    """``python bench.py --gpus 2`` started plainly (no torch.distributed.run around it, as a driver would): the
+    parent starts the two ranks itself and rank 0's JSON line comes through with n_gpus = 2.  The box has one
+    GPU, so the ranks share it over gloo (RCCL refuses two ranks on one device); the path through the launcher,
+    the barriers and the reductions is the one an 8-GPU run takes."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
+    env["QP_BENCH_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--partitions", "64", "--slices", "200", "--no-cpu", "--no-qubo", "--single"],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-3000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 3 and res["scaling"] == "weak"
+    d = res["distributed"]
+    assert d["backend"] == "gloo" and d["world_size"] == 2 and [r["rank"] for r in d["ranks"]] == [0, 1]
+    assert d["host_threads_per_rank"]["local_world_size"] == 2
+    assert len(res["ms_per_step_per_rank"]) == 2 and res["value"] > 0

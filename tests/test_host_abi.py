@@ -453,3 +453,65 @@ def test_apsp_batch_equals_one_at_a_time():
     for s in range(W.shape[0]):
         assert got[s].tobytes() == engine.apsp(C, eu, ev, W[s]).tobytes()
     assert np.isinf(got[4][0, 1]) and got[4][2, 2] == 0
+
+
+def test_host_threads_are_divided_by_the_ranks_on_the_node(monkeypatch):
+    """Every default thread count comes from qp_host_threads: the CPUs this process may run on divided by
+    LOCAL_WORLD_SIZE (the ranks torch.distributed.run started on the node), polling lanes half of that, never
+    less than one; qp_set_host_threads overrides, 0 restores."""
+    import os
+    from quantum_simulator_amd import _lib
+    L = _lib.lib()
+    cpus = len(os.sched_getaffinity(0))
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
+    assert L.qp_set_host_threads(0) == 0
+    assert _lib.host_threads(1 << 20) == cpus
+    assert _lib.host_threads(3) == min(3, cpus)
+    assert _lib.host_threads(8, polling=True) == max(1, min(8, cpus // 2))
+    for ranks in (2, 8, 64):
+        monkeypatch.setenv("LOCAL_WORLD_SIZE", str(ranks))
+        share = max(1, cpus // ranks)
+        assert _lib.host_threads(1 << 20) == share
+        assert _lib.host_threads(16) == min(16, share)
+        assert _lib.host_threads(8, polling=True) == max(1, min(8, share // 2))
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "not a number")
+    assert _lib.host_threads(1 << 20) == cpus
+    try:
+        assert L.qp_set_host_threads(5) == 0
+        assert _lib.host_threads(16) == 5 and _lib.host_threads(2) == 2 and _lib.host_threads(8, polling=True) == 2
+        assert L.qp_set_host_threads(-1) < 0
+    finally:
+        L.qp_set_host_threads(0)
+
+
+def test_bench_starts_its_own_ranks(monkeypatch):
+    """``python bench.py --gpus N`` with no launcher around it: the parent builds a torch.distributed.run command
+    for N ranks on 127.0.0.1 with the same arguments, runs it as a child and returns its exit code."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return subprocess.CompletedProcess(cmd, 7)
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    assert bench.launch_ranks(4) == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert 0 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    k = cmd.index(os.path.join(root, "bench.py"))
+    assert cmd[k + 1:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # and main() takes that road only when no launcher has set WORLD_SIZE
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as exc:
+        bench.main()
+    assert exc.value.code == 7
