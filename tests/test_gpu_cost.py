@@ -99,6 +99,54 @@ def test_cost_v2_v1_v4_golden(gpu, name):
             assert _close(got, gc.cost_v1(p), exact, 2 * ir.nV), (p, "v1 dense", got)
 
 
+@pytest.mark.parametrize("name", ALL_CASES)
+def test_cost_v4_and_comm_matrix_match_the_reference_runs(gpu, name):
+    """qp_slice_cost_v2(QP_V4) and qp_comm_matrix against what the unmodified reference's qubo_placer returned
+    for the same partitions (tests/golden/qubo_cost.json, written by oracle/gen_golden_qubo_cost.py:
+    per_timeslice_cost, Qubo_placer.py:177-207, and the matrix intercorecommatrix draws, :208-245): BFS's and
+    RANDOM's sparse partitions, HQA's dense one, and a BFS partition with one placed qubit removed, on which the
+    reference raises (inf / status 1 here).  All partitions of a case go through one call."""
+    import json
+    import os
+    torch, engine, eng, dev = gpu
+    from conftest import GOLDEN
+    from quantum_simulator_amd.timeslices import CircuitIR
+    gold = json.load(open(os.path.join(GOLDEN, "qubo_cost.json")))[name]
+    gc = load_case(name)
+    ir = CircuitIR(gc.Q, gc.gate_q, gc.gate_mr, slices=gc.slices)
+    dc = engine.DeviceCircuit(ir, dev)
+    ht = engine.DistanceTable(gc.hops.astype(np.float64), dev)
+    names, parts = [], []
+    for pname, entry in gold.items():
+        arr = gc.part(pname.split("_")[0]).copy()[:ir.T]
+        if entry["damage"]:
+            t, q = entry["damage"]
+            arr[t, q] = 0xFF
+        names.append(pname)
+        parts.append(_pad(arr, dc.ldq))
+        parts[-1][:, gc.Q:] = 0
+    A = torch.from_numpy(np.stack(parts)).to(dev)
+    cost = eng.cost_v2(dc, ht, A, engine.QP_V4).cpu().numpy()
+    M, status = eng.comm_matrix(dc, A, gc.C)
+    M, status = M.cpu().numpy(), status.cpu().numpy()
+    for b, pname in enumerate(names):
+        entry = gold[pname]
+        if entry["cost"] is None:
+            assert np.isinf(cost[b]), (pname, cost[b], entry["cost_raises"])
+        else:
+            assert cost[b] == entry["cost"], (pname, cost[b], entry["cost"])
+        if "comm_upper" not in entry:
+            continue
+        if entry["comm_upper"] is None:
+            assert status[b] == 1, (pname, entry["comm_raises"])
+            continue
+        want = np.zeros((gc.C, gc.C), np.int64)
+        for a, c, v in entry["comm_upper"]:
+            want[a, c] = want[c, a] = v
+        assert status[b] == 0 and (M[b] == want).all(), pname
+        assert int(M[b].sum()) == entry["comm_total"]
+
+
 SHAPES = [  # Q, T, C, B, integer weights
     (5, 9, 4, 3, False), (17, 40, 16, 5, True), (63, 70, 64, 4, False), (64, 33, 64, 7, True),
     (100, 21, 100, 3, False), (130, 50, 128, 2, False), (500, 12, 200, 2, True), (1024, 37, 256, 3, True),

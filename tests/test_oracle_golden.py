@@ -288,3 +288,55 @@ def test_cpu_baseline_variants_match_reference_costs(name):
         assert got == gc.cost(p) and searches > 0
         vec = cpu_variants.NumpyCost(gc.slices, gc.gate_q, gc.gate_mr, gc.D).cost(gc.part(p))
         assert abs(vec - gc.cost(p)) <= 1e-12 * abs(gc.cost(p))
+
+
+def _qubo_cost_fixture():
+    import json
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "qubo_cost.json")))
+
+
+def _fixture_partition(gc, pname, entry):
+    """The partition a qubo_cost.json entry was made from: a stored one, or the BFS one with the recorded
+    (slice, qubit) removed."""
+    arr = gc.part(pname.split("_")[0]).copy()
+    if entry["damage"]:
+        t, q = entry["damage"]
+        arr[t, q] = 0xFF
+    return arr
+
+
+def _comm_from_upper(upper, C):
+    M = np.zeros((C, C), np.int64)
+    for a, b, v in upper:
+        M[a, b] = v
+        M[b, a] = v
+    return M
+
+
+@pytest.mark.parametrize("name", ALL_CASES)
+def test_qubo_cost_and_comm_matrix_restatements_match_reference_fixture(name):
+    """oracle.cost_v4 / oracle.comm_matrix against what the unmodified reference's qubo_placer returned for the
+    same partitions (qubo_cost.json: per_timeslice_cost, Qubo_placer.py:177-207; intercorecommatrix, :208-245),
+    including the partitions on which the reference raises."""
+    gold = _qubo_cost_fixture()[name]
+    gc = load_case(name)
+    H = gc.hops.tolist()
+    assert set(gold) >= {"BFS", "RANDOM", "HQA"}
+    for pname, entry in gold.items():
+        arr = _fixture_partition(gc, pname, entry)
+        rows = [[None if c == 0xFF else int(c) for c in row] for row in arr]
+        if entry["cost"] is None:
+            with pytest.raises(O.CostError):
+                O.cost_v4(gc.slices, gc.gate_q, gc.gate_mr, rows, H)
+        else:
+            got = O.cost_v4(gc.slices, gc.gate_q, gc.gate_mr, rows, H)
+            assert got == entry["cost"] and float(got).is_integer(), (pname, got, entry["cost"])
+        if "comm_upper" not in entry:
+            continue
+        if entry["comm_upper"] is None:
+            with pytest.raises(O.CostError):
+                O.comm_matrix(gc.slices, gc.gate_q, gc.gate_mr, rows, gc.C)
+        else:
+            got = np.array(O.comm_matrix(gc.slices, gc.gate_q, gc.gate_mr, rows, gc.C))
+            assert (got == _comm_from_upper(entry["comm_upper"], gc.C)).all(), pname
+            assert int(got.sum()) == entry["comm_total"]
