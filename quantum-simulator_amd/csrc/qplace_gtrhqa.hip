@@ -83,24 +83,57 @@ __device__ inline void lexmin_wave(unsigned long long& key, uint32_t& idx) {
     idx = (uint32_t)__builtin_amdgcn_readlane((int)idx, 63);
 }
 
+// Minimum over each 16-lane row, every lane of the row gets it.  32-bit: the DPP operand folds into v_min_u32.
+template <int CTRL>
+__device__ inline uint32_t dpp_u32(uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, CTRL, 0xF, 0xF, false);
+}
+__device__ inline uint32_t rowmin_u32(uint32_t x) {
+    x = min(x, dpp_u32<0xB1>(x));   // quad_perm [1,0,3,2]
+    x = min(x, dpp_u32<0x4E>(x));   // quad_perm [2,3,0,1]
+    x = min(x, dpp_u32<0x141>(x));  // row_half_mirror
+    x = min(x, dpp_u32<0x140>(x));  // row_mirror
+    return x;
+}
+template <int CTRL>
+__device__ inline unsigned long long min_step_u64(unsigned long long k) {
+    const unsigned long long o = ((unsigned long long)dpp_u32<CTRL>((uint32_t)(k >> 32)) << 32) | dpp_u32<CTRL>((uint32_t)k);
+    return o < k ? o : k;
+}
+__device__ inline unsigned long long rowmin_u64(unsigned long long k) {
+    k = min_step_u64<0xB1>(k);
+    k = min_step_u64<0x4E>(k);
+    k = min_step_u64<0x141>(k);
+    k = min_step_u64<0x140>(k);
+    return k;
+}
+
+constexpr int kPitch = 256;  // entries per row of the prepared tables, whatever C is: a row is 2 KB (fp64) / 512 B (16-bit)
+
 // GTRHQA_placer.py:99-112: sum over the op's two qubits of D[core of the qubit][c], skipping a qubit
 // that is on core c already or on core 0 (label 0 is falsy in the reference's test).  The skips are
 // folded into a copy of the table whose row 0 and diagonal are zero: 0.0 + x + 0.0 == x exactly, so the
 // sum has the bits of the reference's conditional additions.
-__device__ inline double entry(const double* Dz, int C, uint32_t a1, uint32_t a2, uint32_t c) {
-    return Dz[a1 * C + c] + Dz[a2 * C + c];
+__device__ inline double entry(const double* Dz, uint32_t a1, uint32_t a2, uint32_t c) {
+    return Dz[a1 * kPitch + c] + Dz[a2 * kPitch + c];
 }
 
-// Dz = D with row 0 and the diagonal zeroed, Dz16 the same as 16-bit integers; flags[0] = 1 when every entry
+// Dz = D with row 0 and the diagonal zeroed, at a row pitch of 256 entries (columns from C on are zero: no core
+// has them, they are never free), Dz16 the same as 16-bit integers; flags[0] = 1 when every entry
 // of D is finite, flags[1] = 1 when every entry is an integer <= 32767 (integer edge weights): the sum of two
 // then fits 16 bits, is exact in either arithmetic, and the bids can be formed from the small table.
 __global__ void k_gtrhqa_prepare(const double* D, int C, double* Dz, uint16_t* Dz16, int32_t* flags) {
     __shared__ int bad, frac;
     if (threadIdx.x == 0) bad = frac = 0;
     __syncthreads();
-    for (int k = threadIdx.x; k < C * C; k += blockDim.x) {
-        const int r = k / C, c = k - r * C;
-        const double v = D[k];
+    for (int k = threadIdx.x; k < C * kPitch; k += blockDim.x) {
+        const int r = k / kPitch, c = k - r * kPitch;
+        if (c >= C) {
+            Dz[k] = 0.0;
+            Dz16[k] = 0;
+            continue;
+        }
+        const double v = D[r * C + c];
         if (!isfinite(v)) bad = 1;
         const bool small_int = v >= 0.0 && v <= 32767.0 && v == floor(v);
         if (!small_int) frac = 1;
@@ -120,6 +153,9 @@ __global__ void k_gtrhqa_prepare(const double* D, int C, double* Dz, uint16_t* D
 // SMALLINT: the instantiation for tables of small integers (bids from the 16-bit copy).  Which kind a table
 // is, is known on the device only (k_gtrhqa_prepare's flag), so both instantiations are launched and the one
 // that does not apply returns at once; each is compiled for the registers its own bid loop needs.
+//
+// Everything is indexed by core: the reference's columns are the available cores in ascending order, so "first
+// minimum by column" is "first minimum by core", and a core that is not available is simply never free.
 template <int kThreads, bool SMALLINT>
 __global__ __launch_bounds__(kThreads, kThreads == 256 ? (SMALLINT ? QP_GT_WAVES_INT : QP_GT_WAVES) : 4) void k_gtrhqa_place(GpArgs p) {
     constexpr int kWaves = kThreads / kWave;
@@ -129,15 +165,14 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? (SMALLINT ? QP_GT_WAVES
     const int C = p.C, Q = p.Q, ldq = p.ldq;
     uint8_t* rows = smem + p.off_rows;                                 // [2][ldq]
     uint32_t* occ = reinterpret_cast<uint32_t*>(smem + p.off_occ);     // [C]
-    unsigned long long* best = reinterpret_cast<unsigned long long*>(smem + p.off_best);  // [C] by column
-    uint32_t* win = reinterpret_cast<uint32_t*>(smem + p.off_win);     // [C] by column
+    unsigned long long* best = reinterpret_cast<unsigned long long*>(smem + p.off_best);  // [C] by core
+    uint32_t* win = reinterpret_cast<uint32_t*>(smem + p.off_win);     // [C] by core
     double* bid = reinterpret_cast<double*>(smem + p.off_bid);         // [max_ops]
-    int32_t* target = reinterpret_cast<int32_t*>(smem + p.off_target); // [max_ops] column
+    int32_t* target = reinterpret_cast<int32_t*>(smem + p.off_target); // [max_ops] core
     uint32_t* uv = reinterpret_cast<uint32_t*>(smem + p.off_uv);       // [max_ops] u | v << 16
     uint16_t* a12 = reinterpret_cast<uint16_t*>(smem + p.off_a12);     // [max_ops] a1 | a2 << 8
     OpFlags* flags = reinterpret_cast<OpFlags*>(smem + p.off_flags);   // [max_ops]
-    uint8_t* avail = smem + p.off_cores;                               // [C] core id of column j
-    uint8_t* cfree = avail + C;                                        // [C] by column
+    uint8_t* cfree = smem + p.off_cores;                               // [256] by core: 1 = a column of the slice and not taken yet
     uint16_t* need_list = reinterpret_cast<uint16_t*>(smem + p.off_need);  // [max_ops] ops that must bid again
 
     // all distances finite: then every entry is, and the "nothing finite left" test never fires
@@ -173,24 +208,15 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? (SMALLINT ? QP_GT_WAVES
             for (int q = tid; q < Q; q += kThreads) atomicAdd(&occ[min((int)a[q], C - 1)], 1u);  // (a core id >= C is the caller's error; it must not index outside the table)
             __syncthreads();
 
-            // columns: cores with room for a whole op, ascending (GTRHQA_placer.py:81-86)
+            // columns: cores with room for a whole op (GTRHQA_placer.py:81-86)
             {
-                const bool has = tid < C && (int)occ[tid] <= p.cap - 2;
-                const unsigned long long m = __ballot(has);
-                if (lane == 0) s_wave_cnt[wave] = __popcll(m);
-                __syncthreads();
-                int base = 0;
-                for (int w = 0; w < wave; ++w) base += s_wave_cnt[w];
-                if (has) {
-                    const int j = base + __popcll(m & ((1ull << lane) - 1ull));
-                    avail[j] = (uint8_t)tid;
-                    cfree[j] = 1;
+                int mine = 0;
+                for (int c = tid; c < kPitch; c += kThreads) {
+                    const bool has = c < C && (int)occ[c] <= p.cap - 2;
+                    cfree[c] = has ? 1 : 0;
+                    mine += has ? 1 : 0;
                 }
-                if (tid == 0) {
-                    int n = 0;
-                    for (int w = 0; w < kWaves; ++w) n += s_wave_cnt[w];
-                    s_nav = n;
-                }
+                if (mine) atomicAdd(&s_nav, mine);
                 __syncthreads();
             }
             // rows: the slice's counted gates whose qubits sit on different cores, slice order (:72-79)
@@ -230,13 +256,9 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? (SMALLINT ? QP_GT_WAVES
             const int nops = s_nops, nav = s_nav;
             TIC(0);
             if (nops > 0 && nav > 0) {
-                // A 16-lane row of a wave serves one bidding op; lane l of the row looks at columns l, l + 16, ...
-                // Their cores, four to a register:
+                // A 16-lane row of a wave serves one bidding op; lane l of the row looks at cores 32 i + 2 l and
+                // 32 i + 2 l + 1, i = 0 .. 7: 16 bytes of a table row per load, 256 contiguous bytes per row of lanes.
                 const int l16 = lane & 15, rowi = lane >> 4;
-                uint32_t cpk[4] = {0, 0, 0, 0};
-#pragma unroll
-                for (int it = 0; it < 16; ++it)
-                    cpk[it >> 2] |= (uint32_t)avail[min(it * 16 + l16, nav - 1)] << (8 * (it & 3));
                 if (tid == 0) {
                     s_nleft = nops;
                     s_nfree = nav;
@@ -255,8 +277,8 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? (SMALLINT ? QP_GT_WAVES
                             if (!flags[k].left) continue;
                             const uint32_t a1 = a12[k] & 0xFF, a2 = a12[k] >> 8;
                             bool any = false;
-                            for (int j = 0; j < nav && !any; ++j)
-                                any = cfree[j] && isfinite(entry(p.D, C, a1, a2, avail[j]));
+                            for (int c = 0; c < C && !any; ++c)
+                                any = cfree[c] && isfinite(entry(p.D, a1, a2, c));
                             if (any) s_flag = 1;
                         }
                         __syncthreads();
@@ -272,81 +294,108 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? (SMALLINT ? QP_GT_WAVES
                     n_rounds += 1;
                     n_need += nneed;
 #endif
-                    // each of them looks for its cheapest free core (first minimum); four ops per wave step
-                    uint32_t fmask = 0;  // bit it: this lane's column it * 16 + l16 exists and is free
+                    // each of them looks for its cheapest free core (first minimum); four ops per wave step.
+                    // taken: bit 2 i + s set = this lane's core 32 i + 2 l16 + s is not a free column
+                    uint32_t taken = 0;
 #pragma unroll
-                    for (int it = 0; it < 16; ++it) {
-                        const int j = it * 16 + l16;
-                        if (j < nav && cfree[j]) fmask |= 1u << it;
+                    for (int i = 0; i < 8; ++i) {
+                        const uint32_t two = *reinterpret_cast<const uint16_t*>(cfree + 32 * i + 2 * l16);
+                        taken |= (((two & 1u) | ((two >> 7) & 2u)) ^ 3u) << (2 * i);
                     }
                     for (int nb = wave * 4; nb < nneed; nb += kWaves * 4) {
                         const int e = nb + rowi;
                         const bool act = e < nneed;
                         const int k = need_list[act ? e : nb];  // a row without an op of its own repeats the first
                         const uint32_t a1 = a12[k] & 0xFF, a2 = a12[k] >> 8;
-                        // rows of the table as 32-bit byte offsets from its (uniform) base: one register per address
-                        const char* dbase = reinterpret_cast<const char*>(p.D);
-                        const uint32_t r1 = a1 * (uint32_t)C * 8u, r2 = a2 * (uint32_t)C * 8u;
-                        // key = bits of the entry (non-negative doubles order like their bits), idx = column
-                        // with "finite" in bit 16; a lane looks at its columns in ascending order, so "<"
-                        // keeps its first minimum and the row minimum breaks ties by column
-                        unsigned long long key = ~0ull;
-                        uint32_t idx = 0x7FFFFFFFu;
-                        // The 32 loads of a lane's 16 columns are issued together, with no branch between them
-                        // (columns past nav repeat the last one and are masked out by fmask): a step costs one
-                        // memory latency, not one per column.
-                        if constexpr (SMALLINT) {  // integer table: 2-byte loads, 32-bit sums and compares
+                        // key = bits of the entry (non-negative doubles order like their bits); a lane looks at its
+                        // cores in ascending order, so "<" keeps its first minimum; among the lanes of the row the
+                        // smallest core with the row's minimum wins.  A core that is not free gets all ones in the
+                        // key's upper half, which no entry reaches.  The 16 loads of a lane are issued together, with
+                        // no branch between them: a step costs one memory latency.
+                        uint32_t sel = 0;  // position 2 i + s of the lane's minimum
+                        unsigned long long row_key;
+                        uint32_t fin = 1;
+                        if constexpr (SMALLINT) {  // integer table: two 16-bit entries per load, packed 16-bit sums
                             const char* hbase = reinterpret_cast<const char*>(p.D16);
-                            const uint32_t h1 = r1 >> 2, h2 = r2 >> 2;
-                            uint32_t s1[16], s2[16];
+                            const uint32_t h1 = a1 * (uint32_t)(kPitch * 2) + (uint32_t)l16 * 4u, h2 = a2 * (uint32_t)(kPitch * 2) + (uint32_t)l16 * 4u;
+                            uint32_t s1[8], s2[8];
 #pragma unroll
-                            for (int it = 0; it < 16; ++it) {
-                                const uint32_t c2 = ((cpk[it >> 2] >> (8 * (it & 3))) & 0xFFu) * 2u;
-                                s1[it] = *reinterpret_cast<const uint16_t*>(hbase + (h1 + c2));
-                                s2[it] = *reinterpret_cast<const uint16_t*>(hbase + (h2 + c2));
+                            for (int i = 0; i < 8; ++i) {
+                                s1[i] = *reinterpret_cast<const uint32_t*>(hbase + (h1 + i * 64));
+                                s2[i] = *reinterpret_cast<const uint32_t*>(hbase + (h2 + i * 64));
                             }
-                            uint32_t key32 = ~0u, best_it = 0;
+                            uint32_t key32 = 0xFFFF0000u;
 #pragma unroll
-                            for (int it = 0; it < 16; ++it) {
-                                const uint32_t kk = s1[it] + s2[it];
-                                if (((fmask >> it) & 1u) && kk < key32) {
-                                    key32 = kk;
-                                    best_it = (uint32_t)it;
+                            for (int i = 0; i < 8; ++i) {
+                                const uint32_t sum = s1[i] + s2[i];  // each half < 65536: no carry between the halves
+#pragma unroll
+                                for (int sft = 0; sft < 2; ++sft) {
+                                    const uint32_t off = (uint32_t)__builtin_amdgcn_sbfe((int)taken, 2 * i + sft, 1) << 16;  // 0 or 0xFFFF0000
+                                    const uint32_t kk = ((sum >> (16 * sft)) & 0xFFFFu) | off;
+                                    if (kk < key32) {
+                                        key32 = kk;
+                                        sel = (uint32_t)(2 * i + sft);
+                                    }
                                 }
                             }
-                            if (key32 != ~0u) {  // the same bits the fp64 sum of the two (integer) entries has
-                                key = dbits((double)key32);
-                                idx = (best_it * 16u + (uint32_t)l16) | 0x10000u;
-                            }
-                        } else {
-                            double d1[16], d2[16];
+                            const uint32_t m32 = rowmin_u32(key32);
+                            const uint32_t cand = key32 == m32 ? (sel >> 1) * 32u + (sel & 1u) + 2u * (uint32_t)l16 : 0xFFFFu;
+                            sel = rowmin_u32(cand);
+                            row_key = dbits((double)m32);  // the same bits the fp64 sum of the two (integer) entries has
+                        } else if (dfinite) {
+                            const char* dbase = reinterpret_cast<const char*>(p.D);
+                            const uint32_t r1 = a1 * (uint32_t)(kPitch * 8) + (uint32_t)l16 * 16u, r2 = a2 * (uint32_t)(kPitch * 8) + (uint32_t)l16 * 16u;
+                            double2 d1[8], d2[8];
 #pragma unroll
-                            for (int it = 0; it < 16; ++it) {
-                                const uint32_t c8 = ((cpk[it >> 2] >> (8 * (it & 3))) & 0xFFu) * 8u;
-                                d1[it] = *reinterpret_cast<const double*>(dbase + (r1 + c8));
-                                d2[it] = *reinterpret_cast<const double*>(dbase + (r2 + c8));
+                            for (int i = 0; i < 8; ++i) {
+                                d1[i] = *reinterpret_cast<const double2*>(dbase + (r1 + i * 256));
+                                d2[i] = *reinterpret_cast<const double2*>(dbase + (r2 + i * 256));
                             }
+                            unsigned long long key = 0xFFFFFFFF00000000ull;
 #pragma unroll
-                            for (int it = 0; it < 16; ++it) {
-                                const double val = d1[it] + d2[it];
-                                const bool fin = dfinite || isfinite(val);
-                                const unsigned long long kk = dbits(fin ? val : kBig);
-                                if (((fmask >> it) & 1u) && kk < key) {
+                            for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                                for (int sft = 0; sft < 2; ++sft) {
+                                    const double val = sft ? d1[i].y + d2[i].y : d1[i].x + d2[i].x;
+                                    const uint32_t off = (uint32_t)__builtin_amdgcn_sbfe((int)taken, 2 * i + sft, 1);  // 0 or all ones
+                                    const unsigned long long kk = dbits(val) | ((unsigned long long)off << 32);
+                                    if (kk < key) {
+                                        key = kk;
+                                        sel = (uint32_t)(2 * i + sft);
+                                    }
+                                }
+                            }
+                            row_key = rowmin_u64(key);
+                            const uint32_t cand = key == row_key ? (sel >> 1) * 32u + (sel & 1u) + 2u * (uint32_t)l16 : 0xFFFFu;
+                            sel = rowmin_u32(cand);
+                        } else {  // some distance is infinite: such an entry bids 1e12 and cannot win a core (:139, :178)
+                            unsigned long long key = ~0ull;
+                            uint32_t idx = 0x7FFFFFFFu;
+#pragma unroll 4
+                            for (int i = 0; i < 16; ++i) {
+                                const uint32_t c = (uint32_t)((i >> 1) * 32 + (i & 1) + 2 * l16);
+                                const double val = entry(p.D, a1, a2, c);
+                                const bool f = isfinite(val);
+                                const unsigned long long kk = dbits(f ? val : kBig);
+                                if (!((taken >> i) & 1u) && kk < key) {
                                     key = kk;
-                                    idx = (uint32_t)(it * 16 + l16) | (fin ? 0x10000u : 0u);
+                                    idx = c | (f ? 0x10000u : 0u);
                                 }
                             }
+                            lexmin_row(key, idx);
+                            row_key = key;
+                            sel = idx & 0xFFFFu;
+                            fin = (idx >> 16) & 1u;
                         }
-                        lexmin_row(key, idx);
                         if (act && l16 == 0) {
-                            bid[k] = __longlong_as_double((long long)key);
-                            target[k] = (int)(idx & 0xFFFFu);
-                            flags[k] = OpFlags{1, 0, (uint8_t)((idx >> 16) & 1u), 0};
+                            bid[k] = __longlong_as_double((long long)row_key);
+                            target[k] = (int)sel;
+                            flags[k] = OpFlags{1, 0, (uint8_t)fin, 0};
                         }
                     }
-                    for (int j = tid; j < nav; j += kThreads) {
-                        best[j] = ~0ull;
-                        win[j] = ~0u;
+                    for (int c = tid; c < C; c += kThreads) {
+                        best[c] = ~0ull;
+                        win[c] = ~0u;
                     }
                     __syncthreads();         // every thread has read s_nneed and is done with the list
                     if (tid == 0) s_nneed = 0;  // (ordered before the appends below by the barriers in between)
@@ -358,15 +407,15 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? (SMALLINT ? QP_GT_WAVES
                     for (int k = tid; k < nops; k += kThreads)
                         if (flags[k].left && dbits(bid[k]) == best[target[k]]) atomicMin(&win[target[k]], (uint32_t)k);
                     __syncthreads();
-                    for (int j = tid; j < nav; j += kThreads) {
-                        if (!cfree[j] || win[j] == ~0u) continue;
-                        const int k = (int)win[j];
+                    for (int c = tid; c < C; c += kThreads) {
+                        if (!cfree[c] || win[c] == ~0u) continue;
+                        const int k = (int)win[c];
                         if (!flags[k].fin) continue;  // :178-179 a non-finite winner leaves both open
                         flags[k].left = 0;
-                        cfree[j] = 0;
+                        cfree[c] = 0;
                         const uint32_t w = uv[k];
-                        a[w & 0xFFFF] = avail[j];
-                        a[w >> 16] = avail[j];
+                        a[w & 0xFFFF] = (uint8_t)c;
+                        a[w >> 16] = (uint8_t)c;
                         atomicSub(&s_nleft, 1);
                         atomicSub(&s_nfree, 1);
                     }
@@ -405,28 +454,29 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? (SMALLINT ? QP_GT_WAVES
                         }
                         __syncthreads();
                         const uint32_t a1 = a12[k] & 0xFF, a2 = a12[k] >> 8;
-                        double vm = 0.0;
-                        bool mine = false;
-                        if (tid < nav && cfree[tid]) {
-                            const double val = entry(p.D, C, a1, a2, avail[tid]);
-                            const bool fin = isfinite(val);
-                            if (fin) s_flag = 1;
-                            vm = fin ? val : kBig;
-                            mine = true;
-                            atomicMin(&best[0], dbits(vm));
+                        for (int c = tid; c < C; c += kThreads) {
+                            if (!cfree[c]) continue;
+                            const double val = entry(p.D, a1, a2, c);
+                            const bool f = isfinite(val);
+                            if (f) s_flag = 1;
+                            atomicMin(&best[0], dbits(f ? val : kBig));
                         }
                         __syncthreads();
-                        if (mine && dbits(vm) == best[0]) atomicMin(&win[0], (uint32_t)tid);
+                        for (int c = tid; c < C; c += kThreads) {
+                            if (!cfree[c]) continue;
+                            const double val = entry(p.D, a1, a2, c);
+                            if (dbits(isfinite(val) ? val : kBig) == best[0]) atomicMin(&win[0], (uint32_t)c);
+                        }
                         __syncthreads();
                         const bool any = s_flag != 0;
-                        const int j = (int)win[0];
+                        const int c = (int)win[0];
                         __syncthreads();
                         if (any && tid == 0) {
                             flags[k].left = 0;
-                            cfree[j] = 0;
+                            cfree[c] = 0;
                             const uint32_t w = uv[k];
-                            a[w & 0xFFFF] = avail[j];
-                            a[w >> 16] = avail[j];
+                            a[w & 0xFFFF] = (uint8_t)c;
+                            a[w >> 16] = (uint8_t)c;
                             s_nfree -= 1;
                             s_nleft -= 1;
                         }
@@ -455,8 +505,8 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? (SMALLINT ? QP_GT_WAVES
 }  // namespace
 
 extern "C" size_t qp_gtrhqa_workspace(int32_t C) {
-    // fp64 copy, two flags, 16-bit copy
-    return C > 0 ? (size_t)C * C * (sizeof(double) + sizeof(uint16_t)) + 16 : 16;
+    // fp64 copy at a row pitch of 256 entries, two flags, 16-bit copy at the same pitch
+    return C > 0 ? (size_t)C * kPitch * (sizeof(double) + sizeof(uint16_t)) + 16 : 16;
 }
 
 extern "C" int qp_gtrhqa_place(const QpCircuit* circ, const QpDTable* dt, const uint8_t* initial, int64_t B, int32_t ldq,
@@ -474,7 +524,7 @@ extern "C" int qp_gtrhqa_place(const QpCircuit* circ, const QpDTable* dt, const 
         return qp::fail(QP_ENOSPC, "qp_gtrhqa_place: workspace needs %zu bytes, 8-byte aligned", qp_gtrhqa_workspace(dt->C));
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     double* Dz = static_cast<double*>(workspace);
-    int32_t* all_finite = reinterpret_cast<int32_t*>(Dz + (size_t)dt->C * dt->C);
+    int32_t* all_finite = reinterpret_cast<int32_t*>(Dz + (size_t)dt->C * kPitch);
     uint16_t* Dz16 = reinterpret_cast<uint16_t*>(all_finite + 4);
     k_gtrhqa_prepare<<<1, 1024, 0, stream>>>(static_cast<const double*>(dt->table), dt->C, Dz, Dz16, all_finite);
     HIP_TRY(hipGetLastError());
@@ -512,7 +562,7 @@ extern "C" int qp_gtrhqa_place(const QpCircuit* circ, const QpDTable* dt, const 
     p.off_uv = take((size_t)4 * max_ops);
     p.off_a12 = take((size_t)2 * max_ops);
     p.off_flags = take((size_t)4 * max_ops);
-    p.off_cores = take((size_t)2 * dt->C);
+    p.off_cores = take((size_t)kPitch);
     p.off_need = take((size_t)2 * max_ops);
     if (off > 160u * 1024u) return qp::fail(QP_EINVAL, "qp_gtrhqa_place: circuit too wide for the on-chip state (%u bytes)", off);
     const int cus = qp::device_cus();

@@ -1,4 +1,4 @@
-"""Times qp_gtrhqa_place on the benchmark circuit: time_gtrhqa.py [B ...]"""
+"""Times qp_gtrhqa_place on the benchmark circuit: time_gtrhqa.py [uniform|integer] [B ...]"""
 import os
 import random
 import sys
@@ -22,11 +22,17 @@ def main():
     ir = CircuitIR.from_gate_tables(Q, q0, q1)
     dc, eng = DeviceCircuit(ir, dev), Engine(dev)
     random.seed(1234)
-    arch = multicore(16, 16, ncm_qubits=4, ncp_qubits=cap, edge_weight_range=(2.0, 2.0), network_type="mesh")
+    args = sys.argv[1:]
+    wr = (2.0, 2.0)
+    if args and args[0] in ("uniform", "integer"):
+        wr = (1.0, 3.0) if args[0] == "uniform" else (2.0, 2.0)
+        args = args[1:]
+    print("edge weights", wr, flush=True)
+    arch = multicore(16, 16, ncm_qubits=4, ncp_qubits=cap, edge_weight_range=wr, network_type="mesh")
     nodes, eu, ev, w = graph_tables(arch.network)
     dt = DistanceTable(apsp(len(nodes), eu, ev, w), dev)
     rng = np.random.default_rng(0)
-    for B in [int(x) for x in sys.argv[1:]] or [64, 256]:
+    for B in [int(x) for x in args] or [64, 256]:
         slots = np.repeat(np.arange(C), cap)
         init = np.stack([rng.permutation(slots)[:Q] for _ in range(B)]).astype(np.uint8)
         init[0] = np.arange(Q) // cap
