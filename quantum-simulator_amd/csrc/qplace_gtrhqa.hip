@@ -302,6 +302,9 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? (SMALLINT ? QP_GT_WAVES
                         const uint32_t two = *reinterpret_cast<const uint16_t*>(cfree + 32 * i + 2 * l16);
                         taken |= (((two & 1u) | ((two >> 7) & 2u)) ^ 3u) << (2 * i);
                     }
+                    bool isfree[16];  // the same per position, held as lane masks for the compares below
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) isfree[j] = ((taken >> j) & 1u) == 0;
                     for (int nb = wave * 4; nb < nneed; nb += kWaves * 4) {
                         const int e = nb + rowi;
                         const bool act = e < nneed;
@@ -324,15 +327,14 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? (SMALLINT ? QP_GT_WAVES
                                 s1[i] = *reinterpret_cast<const uint32_t*>(hbase + (h1 + i * 64));
                                 s2[i] = *reinterpret_cast<const uint32_t*>(hbase + (h2 + i * 64));
                             }
-                            uint32_t key32 = 0xFFFF0000u;
+                            uint32_t key32 = ~0u;
 #pragma unroll
                             for (int i = 0; i < 8; ++i) {
                                 const uint32_t sum = s1[i] + s2[i];  // each half < 65536: no carry between the halves
 #pragma unroll
                                 for (int sft = 0; sft < 2; ++sft) {
-                                    const uint32_t off = (uint32_t)__builtin_amdgcn_sbfe((int)taken, 2 * i + sft, 1) << 16;  // 0 or 0xFFFF0000
-                                    const uint32_t kk = ((sum >> (16 * sft)) & 0xFFFFu) | off;
-                                    if (kk < key32) {
+                                    const uint32_t kk = sft ? sum >> 16 : sum & 0xFFFFu;
+                                    if (isfree[2 * i + sft] && kk < key32) {
                                         key32 = kk;
                                         sel = (uint32_t)(2 * i + sft);
                                     }
@@ -345,23 +347,27 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? (SMALLINT ? QP_GT_WAVES
                         } else if (dfinite) {
                             const char* dbase = reinterpret_cast<const char*>(p.D);
                             const uint32_t r1 = a1 * (uint32_t)(kPitch * 8) + (uint32_t)l16 * 16u, r2 = a2 * (uint32_t)(kPitch * 8) + (uint32_t)l16 * 16u;
-                            double2 d1[8], d2[8];
+                            unsigned long long key = ~0ull;
+                            // two batches of eight loads: the registers of one batch leave room for six waves per SIMD,
+                            // whose loads overlap (all sixteen at once cost more in occupancy than they saved in waiting)
 #pragma unroll
-                            for (int i = 0; i < 8; ++i) {
-                                d1[i] = *reinterpret_cast<const double2*>(dbase + (r1 + i * 256));
-                                d2[i] = *reinterpret_cast<const double2*>(dbase + (r2 + i * 256));
-                            }
-                            unsigned long long key = 0xFFFFFFFF00000000ull;
+                            for (int h = 0; h < 2; ++h) {
+                                double2 d1[4], d2[4];
 #pragma unroll
-                            for (int i = 0; i < 8; ++i) {
+                                for (int i = 0; i < 4; ++i) {
+                                    d1[i] = *reinterpret_cast<const double2*>(dbase + (r1 + (4 * h + i) * 256));
+                                    d2[i] = *reinterpret_cast<const double2*>(dbase + (r2 + (4 * h + i) * 256));
+                                }
 #pragma unroll
-                                for (int sft = 0; sft < 2; ++sft) {
-                                    const double val = sft ? d1[i].y + d2[i].y : d1[i].x + d2[i].x;
-                                    const uint32_t off = (uint32_t)__builtin_amdgcn_sbfe((int)taken, 2 * i + sft, 1);  // 0 or all ones
-                                    const unsigned long long kk = dbits(val) | ((unsigned long long)off << 32);
-                                    if (kk < key) {
-                                        key = kk;
-                                        sel = (uint32_t)(2 * i + sft);
+                                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                                    for (int sft = 0; sft < 2; ++sft) {
+                                        const double val = sft ? d1[i].y + d2[i].y : d1[i].x + d2[i].x;
+                                        const unsigned long long kk = dbits(val);
+                                        if (isfree[8 * h + 2 * i + sft] && kk < key) {
+                                            key = kk;
+                                            sel = (uint32_t)(8 * h + 2 * i + sft);
+                                        }
                                     }
                                 }
                             }
