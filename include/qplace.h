@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define QP_VERSION 203
+#define QP_VERSION 204
 
 #define QP_OK 0
 #define QP_EINVAL (-1)   /* bad argument (shape, alignment, range) */
@@ -124,6 +124,12 @@ typedef struct QpDTable {
                           what lets a table of more than 134 cores work out of on-chip memory (pair counts
                           instead of look-ups).  0 is always correct. */
     int32_t reserved_;
+    double grid_scale; /* QP_DT_F64 only: when positive and grid.valid is set, every entry of the table equals
+                          grid_scale * (grid.wx * dx + grid.wy * dy) to within a few units in the last place
+                          (qp_dtable_scaled_grid_metric checked each one): a network whose links all carry the same
+                          real weight, such as the two-core mesh of example_config.txt:1-12 with its one link
+                          (multicore.py:159-161 draws it from random.uniform).  The dense cost kernel may then count
+                          hops with the closed form and multiply once per partition.  0 is always correct. */
 } QpDTable;
 
 int qp_version(void);
@@ -230,6 +236,15 @@ int qp_dtable_pack(const double* D_host, int32_t C, void* staging /* host */, si
 
 /* Tests whether a host distance matrix is a grid metric (see QpGridMetric); *out is zeroed when not. */
 int qp_dtable_grid_metric(const double* D_host, int32_t C, QpGridMetric* out);
+
+/* The same test for a real-valued matrix that is one positive real number times an integer grid metric:
+ * s = the smallest positive entry, M = D / s rounded to integers; accepted when |D[a][b] - s * M[a][b]| <=
+ * rel_tol * D[a][b] for every pair and M passes qp_dtable_grid_metric.  *out describes M and *scale_out = s;
+ * both are zeroed when the matrix is not of this form (or is an integer matrix already: scale 1 is
+ * qp_dtable_grid_metric's case).  The distances the reference adds up are sums of k equal link weights formed
+ * one addition at a time (Placer.py:63-76), so they differ from k * s by rounding only; a cost formed as
+ * s * (number of hops) differs from the reference's sum by that much per term. */
+int qp_dtable_scaled_grid_metric(const double* D_host, int32_t C, double rel_tol, QpGridMetric* out, double* scale_out);
 
 /* 1 if |D[a][b] - D[b][a]| <= rel_tol * max(|D[a][b]|, |D[b][a]|) for every pair (infinite entries must
  * match exactly, NaN never passes), else 0; negative on bad arguments.  Distances over an undirected graph

@@ -36,7 +36,7 @@ class QpGridMetric(C.Structure):
 
 class QpDTable(C.Structure):
     _fields_ = [("kind", C.c_int32), ("C", C.c_int32), ("table", C.c_void_p), ("grid", QpGridMetric),
-                ("symmetric", C.c_int32), ("reserved_", C.c_int32)]
+                ("symmetric", C.c_int32), ("reserved_", C.c_int32), ("grid_scale", C.c_double)]
 
 
 class QpQuboKron(C.Structure):
@@ -86,6 +86,7 @@ EXPORTS = {
                                  C.POINTER(C.c_size_t)]),
     "qp_dtable_grid_metric": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(QpGridMetric)]),
     "qp_dtable_symmetric": (C.c_int, [C.c_void_p, C.c_int32, C.c_double]),
+    "qp_dtable_scaled_grid_metric": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.POINTER(QpGridMetric), C.POINTER(C.c_double)]),
     "qp_make_space": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                 C.c_int32, C.c_void_p]),
     "qp_place_sparse": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,

@@ -449,6 +449,43 @@ void qp::make_space_row(uint8_t* ar, int64_t* oc, int32_t Q, int32_t C, int32_t 
     }
 }
 
+extern "C" int qp_dtable_scaled_grid_metric(const double* D, int32_t C, double rel_tol, QpGridMetric* out, double* scale_out) try {
+    if (!D || !out || !scale_out || C <= 0 || C > 256 || !(rel_tol >= 0.0))
+        return qp::fail(QP_EINVAL, "qp_dtable_scaled_grid_metric: bad argument");
+    *out = QpGridMetric{};
+    *scale_out = 0.0;
+    if (C == 1) return QP_OK;
+    const size_t n = (size_t)C * C;
+    double s = 0.0;
+    bool integral = true;
+    for (size_t k = 0; k < n; ++k) {
+        if (k / C == k % C) continue;
+        const double x = D[k];
+        if (!(std::isfinite(x) && x > 0.0)) return QP_OK;
+        if (x != std::floor(x)) integral = false;
+        if (s == 0.0 || x < s) s = x;
+    }
+    if (integral || s <= 0.0) return QP_OK;
+    std::vector<double> M(n, 0.0);
+    for (size_t k = 0; k < n; ++k) {
+        if (k / C == k % C) continue;
+        const double m = std::nearbyint(D[k] / s);
+        if (!(m >= 1.0 && m <= 65534.0) || std::fabs(D[k] - m * s) > rel_tol * D[k]) return QP_OK;
+        M[k] = m;
+    }
+    QpGridMetric g{};
+    if (int rc = qp_dtable_grid_metric(M.data(), C, &g)) return rc;
+    if (g.valid) {
+        *out = g;
+        *scale_out = s;
+    }
+    return QP_OK;
+} catch (const std::exception& e) {
+    return qp::fail(QP_ENOMEM, "qp_dtable_scaled_grid_metric: %s", e.what());
+} catch (...) {
+    return qp::fail(QP_ENOMEM, "qp_dtable_scaled_grid_metric: unknown exception");
+}
+
 extern "C" int qp_dtable_symmetric(const double* D, int32_t C, double rel_tol) try {
     if (!D || C <= 0 || !(rel_tol >= 0.0)) return qp::fail(QP_EINVAL, "qp_dtable_symmetric: bad arguments");
     for (int32_t a = 0; a < C; ++a) {

@@ -1995,12 +1995,13 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void k_cost_v3_wid
 }
 
 // out[b] = partial[0*B + b] + partial[1*B + b] + ... in chunk order.
-__global__ void k_sum_chunks(const double* partial, int64_t B, int32_t nchunks, double* out) {
+// scale: 1, or the real number a scaled grid metric multiplies its hop counts by (the partial sums are then integers)
+__global__ void k_sum_chunks(const double* partial, int64_t B, int32_t nchunks, double* out, double scale = 1.0) {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     double s = 0.0;
     for (int32_t c = 0; c < nchunks; ++c) s += partial[(size_t)c * B + b];
-    out[b] = s;
+    out[b] = scale == 1.0 ? s : s * scale;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2673,6 +2674,12 @@ __global__ __launch_bounds__(256) void k_cost_matrix(CmArgs p) {
 // ------------------------------------------------------------------------------------------------
 
 // Byte-replicated masks and weights of a grid metric, as the closed-form kernels take them.
+// A closed form stands for the table: an integer grid metric, or a real number times one.
+bool has_grid_form(const QpDTable* dt) {
+    return dt->grid.valid && (dt->kind == QP_DT_U16 || (dt->kind == QP_DT_F64 && dt->grid_scale > 0.0));
+}
+double grid_scale_of(const QpDTable* dt) { return dt->kind == QP_DT_F64 ? dt->grid_scale : 1.0; }
+
 int fill_grid_args(V3Args& p, const QpDTable* dt) {
     const QpGridMetric& g = dt->grid;
     if (g.xbits < 0 || g.xbits > 8 || (g.wrap_x && g.wrap_x != (1 << g.xbits)) || g.wrap_x > 128 ||
@@ -2780,7 +2787,7 @@ int slice_cost_v3_impl(const QpCircuit* circ, const QpDTable* dt, const uint8_t*
     double* wide_fold = nullptr;
     if (!narrow) {
         if (ldq / 16 > kWidePieces * kV3Threads) return qp::fail(QP_EINVAL, "qp_slice_cost_v3: rows longer than 65536 bytes");
-        const bool gridpath = dt->kind == QP_DT_U16 && dt->grid.valid;
+        const bool gridpath = has_grid_form(dt);
         // the table (if it fits beside one set of strips) and one or two strips of a row per group
         wide_strips = (size_t)kV3Threads * 16 * (ldq / 16 <= kV3Threads ? 1 : kWidePieces);
         if (!gridpath && tab_padded + wide_strips <= (size_t)kLdsBytes) wide_tab = tab_padded;
@@ -2798,7 +2805,7 @@ int slice_cost_v3_impl(const QpCircuit* circ, const QpDTable* dt, const uint8_t*
         // fp64 table that does not fit beside the strips but is symmetric to rounding, rows of up to 16 KB: pair
         // counts instead of gathers from device memory.  One 1024-thread workgroup per CU (the counters take
         // 128 KB); long items, about 8 per workgroup, since every item ends with a pass over all counters
-        if (dt->kind == QP_DT_F64 && dt->symmetric && dt->C >= 2 && wide_tab == 0 && ldq / 16 <= kV3Threads) {
+        if (dt->kind == QP_DT_F64 && dt->symmetric && dt->C >= 2 && wide_tab == 0 && !gridpath && ldq / 16 <= kV3Threads) {
             int P1 = 128;
             while (P1 < ldq / 16) P1 *= 2;
             const int64_t want = ((int64_t)T * B + (int64_t)cus * 8 - 1) / ((int64_t)cus * 8);
@@ -2849,7 +2856,7 @@ int slice_cost_v3_impl(const QpCircuit* circ, const QpDTable* dt, const uint8_t*
         q.nitems = (int64_t)gchunks * q.nbgroups;
         const size_t gstrips = (size_t)kV3Waves * (G + 1) * ldq;
         if (dt->kind == QP_DT_F64 && dt->symmetric && dt->C >= 2 && tab_padded + gstrips > (size_t)kLdsBytes &&
-            (int64_t)T * ldq >= 32768) {
+            !has_grid_form(dt) && (int64_t)T * ldq >= 32768) {
             // fp64 table too large for LDS, symmetric to rounding, partitions of 32 KB or more: pair counts, a
             // workgroup per item (about 8 items per workgroup: every item ends with a pass over all counters, which
             // costs as much as counting 30 KB of rows; below that size the gathers from device memory are no slower)
@@ -2876,7 +2883,7 @@ int slice_cost_v3_impl(const QpCircuit* circ, const QpDTable* dt, const uint8_t*
             }
         }
         if (workspace_bytes >= (size_t)gchunks * B * sizeof(double)) {
-            const bool gridpath = dt->kind == QP_DT_U16 && dt->grid.valid;
+            const bool gridpath = has_grid_form(dt);
             const size_t strips = gstrips;
             const size_t tab256 = (size_t)dt->C * 256 * esz;
             // what the table takes in LDS and how it is addressed
@@ -2932,14 +2939,14 @@ int slice_cost_v3_impl(const QpCircuit* circ, const QpDTable* dt, const uint8_t*
             const unsigned ggrid = (unsigned)std::min<int64_t>((int64_t)cus * std::max(per_cu, 1), (q.nitems + waves - 1) / waves);
             kern<<<ggrid, threads, lds, stream>>>(q);
             HIP_TRY(hipGetLastError());
-            k_sum_chunks<<<(unsigned)((B + 255) / 256), 256, 0, stream>>>(q.partial, B, gchunks, out);
+            k_sum_chunks<<<(unsigned)((B + 255) / 256), 256, 0, stream>>>(q.partial, B, gchunks, out, gridpath ? grid_scale_of(dt) : 1.0);
             HIP_TRY(hipGetLastError());
             return QP_OK;
         }
     }
     if (narrow) {
         const bool rowpath = ldq > 512 && circ->edges_sched != nullptr && circ->sched_ptr != nullptr && circ->nE > 0;
-        const bool gridpath = dt->kind == QP_DT_U16 && dt->grid.valid;
+        const bool gridpath = has_grid_form(dt);
         const size_t strips = rowpath ? (size_t)kV3Waves * (gridpath ? kGridStrip : ldq) : (size_t)kV3Waves * (p.G + 1) * ldq;
         const size_t tab256 = (size_t)dt->C * 256 * esz;
         int mode = kTabGlobal;
@@ -2966,7 +2973,7 @@ int slice_cost_v3_impl(const QpCircuit* circ, const QpDTable* dt, const uint8_t*
             const unsigned ggrid = (unsigned)std::min<int64_t>((int64_t)cus * std::max(per_cu, 1), (p.nitems + kV3Waves - 1) / kV3Waves);
             kern<<<ggrid, kV3Threads, strips, stream>>>(p);
             HIP_TRY(hipGetLastError());
-            k_sum_chunks<<<(unsigned)((B + 255) / 256), 256, 0, stream>>>(p.partial, B, nchunks, out);
+            k_sum_chunks<<<(unsigned)((B + 255) / 256), 256, 0, stream>>>(p.partial, B, nchunks, out, grid_scale_of(dt));
             HIP_TRY(hipGetLastError());
             return QP_OK;
         }
@@ -3056,7 +3063,7 @@ int slice_cost_v3_impl(const QpCircuit* circ, const QpDTable* dt, const uint8_t*
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         kern<<<grid, kV3Threads, lds, stream>>>(p);
     } else {
-        const bool gridpath = dt->kind == QP_DT_U16 && dt->grid.valid;
+        const bool gridpath = has_grid_form(dt);
         const bool one = ldq / 16 <= kV3Threads;  // one piece per thread
         const bool half = wide_threads < kV3Threads, two = wide_two, tab_lds = wide_tab > 0;
         const int threads = wide_threads;
@@ -3087,7 +3094,8 @@ int slice_cost_v3_impl(const QpCircuit* circ, const QpDTable* dt, const uint8_t*
         kern<<<grid, threads, lds, stream>>>(p);
     }
     HIP_TRY(hipGetLastError());
-    k_sum_chunks<<<(unsigned)((B + 255) / 256), 256, 0, stream>>>(p.partial, B, nchunks, out);
+    k_sum_chunks<<<(unsigned)((B + 255) / 256), 256, 0, stream>>>(p.partial, B, nchunks, out,
+                                                                   (!narrow && !wide_pairs && has_grid_form(dt)) ? grid_scale_of(dt) : 1.0);
     HIP_TRY(hipGetLastError());
     return QP_OK;
 }

@@ -154,6 +154,7 @@ class DeviceCircuit:
 # |D[a][b] - D[b][a]| relative to the entry below which a matrix counts as symmetric: costs are compared
 # at 1e-12 relative, a symmetrised entry is off by at most half the asymmetry
 SYMMETRY_TOLERANCE = 1e-13
+SCALED_GRID_TOLERANCE = 1e-13  # a distance of k equal links against k times the link weight: rounding of k - 1 additions
 
 
 class DistanceTable:
@@ -179,12 +180,18 @@ class DistanceTable:
         # (undirected graphs), which lets a table too large for on-chip memory be replaced by pair counts
         self.table_only = QpDTable(self.kind, self.C, self._packed.data_ptr())
         self.grid = QpGridMetric()
+        self.grid_scale = 0.0
         if self.kind == QP_DT_U16:
             check(lib().qp_dtable_grid_metric(ptr(self.D), self.C, C.byref(self.grid)))
+        else:
+            # one real weight on every link (the shipped example's two-core mesh): hop counts by closed form, times it
+            scale = C.c_double(0.0)
+            check(lib().qp_dtable_scaled_grid_metric(ptr(self.D), self.C, SCALED_GRID_TOLERANCE, C.byref(self.grid), C.byref(scale)))
+            self.grid_scale = scale.value
         self.symmetric = lib().qp_dtable_symmetric(ptr(self.D), self.C, SYMMETRY_TOLERANCE)
         check(min(self.symmetric, 0))
         self.packed = QpDTable(self.kind, self.C, self._packed.data_ptr(), self.grid,
-                               self.symmetric if self.kind == QP_DT_F64 else 0)
+                               self.symmetric if self.kind == QP_DT_F64 else 0, 0, self.grid_scale)
         if self.kind == QP_DT_F64:
             self._f64 = self._packed
         else:

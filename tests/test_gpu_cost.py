@@ -458,6 +458,54 @@ def test_cost_v3_grid_metric(gpu, topo, nx, ny, wt, closed, Q, T):
     assert got[0] == want
 
 
+@pytest.mark.parametrize("topo,nx,ny,wt,closed,Q,T", [
+    ("mesh", 2, 1, 1.8444218515250481, True, 256, 60),   # the shipped example's machine: one link (example_config.txt:1-12)
+    ("mesh", 2, 1, 1.5, True, 40, 7),
+    ("mesh", 4, 4, 0.1, True, 100, 30),                  # 0.1 + 0.1 + 0.1 != 0.3: entries differ from hops * w by rounding
+    ("mesh", 16, 16, 2.75, True, 1024, 9),
+    ("mesh", 16, 16, 1.0 / 3.0, True, 600, 12),
+    ("torus", 8, 8, 1.37, True, 63, 40),
+    ("line", 64, 1, 2.5, True, 200, 11),
+    ("line", 256, 1, 0.7, True, 1500, 4),
+    ("mesh", 3, 3, 1.5, False, 30, 10),                  # no power-of-two row length: look-ups
+    ("star", 8, 1, 1.5, False, 30, 10),
+])
+def test_cost_v3_scaled_grid_metric(gpu, topo, nx, ny, wt, closed, Q, T):
+    """One real weight on every link (what multicore.py:159-161 draws for a one-link machine, or any
+    edge_weight_range (w, w)): the table is w times an integer grid metric up to the rounding of its
+    entries, and the dense cost then counts hops by closed form and multiplies once.  Against the table
+    look-ups of the same launch and against the oracle's sum of the table's own entries: 1e-12."""
+    torch, engine, eng, dev = gpu
+    from quantum_simulator_amd import layered_gate_arrays
+    from quantum_simulator_amd.multicore import multicore
+    from quantum_simulator_amd.timeslices import CircuitIR
+    arch = multicore(nx, ny, ncp_qubits=4, edge_weight_range=(wt, wt), network_type=topo)
+    dt = engine.DistanceTable.from_network(arch.network, dev)
+    assert dt.kind == engine.QP_DT_F64
+    assert bool(dt.grid.valid) == closed and (dt.grid_scale == wt) == closed, (dt.grid.valid, dt.grid_scale)
+    C = dt.C
+    rng = np.random.default_rng(Q + T + C)
+    q0, q1, _ = layered_gate_arrays(Q, T, 0.7, seed=Q + C)
+    keep = rng.random(len(q0)) > 0.2
+    ir = CircuitIR.from_gate_tables(Q, q0[keep], q1[keep])
+    dc = engine.DeviceCircuit(ir, dev)
+    B = 3
+    A = rng.integers(0, C, size=(B, ir.T, dc.ldq), dtype=np.uint8)
+    A[:, :, Q:] = rng.integers(0, 256, size=(B, ir.T, dc.ldq - Q), dtype=np.uint8)
+    Ad = torch.from_numpy(A).to(dev)
+    got = eng.cost_v3(dc, dt, Ad).cpu().numpy()
+    tab = eng.cost_v3(dc, dt, Ad, table="table").cpu().numpy()
+    Dl = dt.D.tolist()
+    for b in range(B):
+        assert _close(got[b], tab[b], False), (b, got[b], tab[b])
+        terms = O.cost_v3_terms(ir.slices, ir.gate_q, ir.gate_mr, A[b, :, :Q].tolist(), Dl)
+        assert _close(got[b], math.fsum(terms), False), (b, got[b], math.fsum(terms))
+    # the entry point without a workspace takes the same road
+    out = torch.empty(B, dtype=torch.float64, device=dev)
+    eng.cost_v3_static(dc, dt, Ad, out)
+    assert out.cpu().numpy().tobytes() == got.tobytes()
+
+
 @pytest.mark.parametrize("Q,T,C,B,integer", [s for s in SHAPES if s[2] <= 255][:10])
 def test_cost_v2_random(gpu, Q, T, C, B, integer):
     torch, engine, eng, dev = gpu

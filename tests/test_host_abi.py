@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in qplace.h but not exported"
     assert declared == set(_lib.EXPORTS), "ctypes table and header disagree"
-    assert _lib.lib().qp_version() == 203
+    assert _lib.lib().qp_version() == 204
 
 
 @pytest.mark.parametrize("name", ALL_CASES)
@@ -515,3 +515,41 @@ def test_bench_starts_its_own_ranks(monkeypatch):
     with pytest.raises(SystemExit) as exc:
         bench.main()
     assert exc.value.code == 7
+
+
+def test_scaled_grid_metric_detection():
+    """qp_dtable_scaled_grid_metric: one real weight on every link of a mesh / line / torus whose row length is a
+    power of two gives scale = that weight and the hop metric; integer matrices (qp_dtable_grid_metric's own
+    case), random weights, other topologies and matrices with an infinite entry are refused."""
+    import random
+    from quantum_simulator_amd.multicore import graph_tables, multicore
+    L = _lib.lib()
+
+    def probe(D):
+        g, s = _lib.QpGridMetric(), ctypes.c_double(-1.0)
+        D = np.ascontiguousarray(D, np.float64)
+        assert L.qp_dtable_scaled_grid_metric(_lib.ptr(D), D.shape[0], 1e-13, ctypes.byref(g), ctypes.byref(s)) == 0
+        return g, s.value
+
+    def table(topo, nx, ny, wr):
+        random.seed(5)
+        arch = multicore(nx, ny, ncp_qubits=4, edge_weight_range=wr, network_type=topo)
+        nodes, eu, ev, w = graph_tables(arch.network)
+        return engine.apsp(len(nodes), eu, ev, w)
+
+    for topo, nx, ny, w, xbits, wrap in (("mesh", 2, 1, 1.8444218515250481, 0, (0, 0)), ("mesh", 4, 4, 0.1, 2, (0, 0)),
+                                         ("mesh", 16, 16, 1.0 / 3.0, 4, (0, 0)), ("torus", 8, 8, 1.37, 3, (8, 8)),
+                                         ("line", 64, 1, 2.5, None, (0, 0))):
+        g, s = probe(table(topo, nx, ny, (w, w)))
+        assert g.valid == 1 and s == w and (g.wrap_x, g.wrap_y) == wrap, (topo, g.valid, s)
+        if nx > 2 and ny > 2:
+            assert g.xbits == xbits and g.wx == 1 and g.wy == 1
+    for D in (table("mesh", 4, 4, (2.0, 2.0)), table("mesh", 4, 4, (1.0, 3.0)), table("mesh", 3, 3, (1.5, 1.5)),
+              table("star", 8, 1, (1.5, 1.5)), table("all_to_all", 2, 2, (1.5, 1.5))):
+        g, s = probe(D)
+        assert g.valid == 0 and s == 0.0, (g.valid, s)
+    Dinf = table("mesh", 4, 4, (1.5, 1.5))
+    Dinf[0, 5] = np.inf
+    g, s = probe(Dinf)
+    assert g.valid == 0 and s == 0.0
+    assert L.qp_dtable_scaled_grid_metric(None, 4, 1e-13, None, None) < 0
