@@ -150,10 +150,12 @@ def lib():
         # is the one both end up using.  If this library's system copy came first (host helpers called before
         # anything touched torch), torch would later load a second runtime and device calls from here would
         # fail with "no ROCm-capable device is detected".
-        try:
-            import torch  # noqa: F401
-        except ImportError:
-            pass
+        # (QPLACE_NO_TORCH: a host-only build of the library under a sanitizer, which must not pull in the HIP runtime.)
+        if not os.environ.get("QPLACE_NO_TORCH"):
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in EXPORTS.items():
             fn = getattr(L, name)  # AttributeError if the symbol is not exported
