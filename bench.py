@@ -59,7 +59,65 @@ def make_partitions(torch, dev, B, T, Q, ldq, C, cap, pmove, seed):
     return A
 
 
-def bench_qubo(torch, dev, rank, sweeps, replicas):
+def qubo_cpu_baseline(torch, dev, qm, dq, names, seconds):
+    """The CPU figure beside spin-flips/s: oracle/qubo_anneal.c, a plain sequential single-flip Metropolis annealer
+    (what neal's sampler does, Qubo_placer.py:139-140) on the same model written out as a sparse matrix by the oracle
+    (oracle/qubo_cpu.py), same temperature range, one replica per thread.  The energy of every final state is
+    checked against the GPU's exact-energy kernel."""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import placer_oracle as O, qubo_cpu
+    act, inter = O.qubo_slices(qm.ir.slices, qm.ir.gate_q, names)
+    sm = qubo_cpu.SparseModel(act, inter, qm.C, qm.cap, qm.H)
+    assert sm.N == qm.N
+    # compact (oracle) order -> position in the product's padded state vector
+    index = np.empty(sm.N, np.int64)
+    for t in range(qm.T):
+        for j in range(qm.C):
+            for i in range(int(qm.n[t])):
+                index[sm.var_x(t, j, i)] = qm.var_x(t, j, i)
+            for p in range(qm.cap):
+                index[sm.var_y(t, j, p)] = qm.var_y(t, j, p)
+    hot, cold = qm.beta_range()
+    rng = np.random.default_rng(11)
+
+    def one(seed, sweeps):
+        st = np.zeros(sm.N, np.int8)
+        e0 = sm.energy(st)
+        d, acc = sm.anneal(st, sweeps, hot, cold, seed)
+        return st, e0 + d
+
+    t0 = time.perf_counter()
+    one(1, 2)
+    per_sweep = (time.perf_counter() - t0) / 2
+    sweeps = int(max(4, min(1000, seconds / 2 / max(per_sweep, 1e-6))))
+    t0 = time.perf_counter()
+    st1, e1 = one(2, sweeps)
+    t_one = time.perf_counter() - t0
+    cores = max(1, min(len(os.sched_getaffinity(0)), int(os.environ.get("OMP_NUM_THREADS", "1024"))))
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as pool:
+        finals = list(pool.map(lambda k: one(100 + k, sweeps), range(cores)))
+    t_all = time.perf_counter() - t0
+    # every final state through the GPU's exact energy (128 states per call)
+    states = [st1] + [f[0] for f in finals]
+    want = [e1] + [f[1] for f in finals]
+    X = np.zeros((128 * ((len(states) + 127) // 128), qm.Npad), np.int8)
+    for k, st in enumerate(states):
+        X[k, index] = st
+    got = dq.energy(torch.from_numpy(X).to(dev)).cpu().numpy()[:len(states)]
+    if [int(g) for g in got] != [int(w) for w in want]:
+        raise SystemExit(f"parity failure: CPU annealer energies {want[:4]} vs GPU energy kernel {got[:4].tolist()}")
+    return {"value": sm.N * sweeps * cores / t_all, "unit": "spin-flip attempts/s", "cores": cores, "kind": "port",
+            "one_core_attempts_per_s": sm.N * sweeps / t_one, "sweeps": sweeps,
+            "best_energy": int(min(want)),
+            "sample": f"{cores} replicas x {sweeps} sweeps over the same {sm.N} variables through oracle/qubo_anneal.c "
+                      f"(sequential single-flip Metropolis on the objective as a sparse matrix of {len(sm.col)} couplings, "
+                      f"gcc -O2), one replica per thread, {t_all:.1f} s; the energy of every final state equals the GPU "
+                      f"energy kernel's"}
+
+
+def bench_qubo(torch, dev, rank, sweeps, replicas, cpu_seconds=0.0):
     """cfg4: 256-qubit layered circuit x 8 slices on a 4x4 mesh (16 cores, capacity 20): N = 35 328
     binary variables, ``replicas`` annealing replicas per GPU.  Returns spin-flip attempts/s of the
     annealer and the int8 MFMA rate of the exact-energy contraction."""
@@ -94,7 +152,13 @@ def bench_qubo(torch, dev, rank, sweeps, replicas):
     ms = ev0.elapsed_time(ev1) / reps
     nnz, mfma_macs, dense_macs = qm.coupling_counts()
     sec = ms * 1e-3
-    return {"workload": f"cfg4: layered {Q}q x {T} slices, mesh 4x4, cap {cap}: N={qm.N} variables, {R} replicas/GPU",
+    cpu = None
+    if cpu_seconds > 0:
+        try:
+            cpu = qubo_cpu_baseline(torch, dev, qm, dq, [f"q[{i}]" for i in range(Q)], cpu_seconds)
+        except MemoryError as exc:
+            cpu = {"error": f"{type(exc).__name__}: {exc}"}
+    return {"cpu_baseline": cpu, "workload": f"cfg4: layered {Q}q x {T} slices, mesh 4x4, cap {cap}: N={qm.N} variables, {R} replicas/GPU",
             "sweeps": sweeps, "spin_flip_attempts_per_s": qm.N * R * sweeps / t_sa, "anneal_s": t_sa,
             "best_energy": int(e.min().item()), "energy_ms": ms,
             "useful_macs": nnz * R, "mfma_macs": mfma_macs * R, "dense_macs": dense_macs * R,
@@ -149,8 +213,11 @@ def bench_cost_matrix(torch, dev, dc, ir, D, B, steps):
 
 def bench_shipped(dev, rank=0, world=1):
     """The reference's shipped circuits (gate tables from tests/golden; the QASM files themselves do not travel):
-    batches of whole placements + their costs, as the driver runs a config's repeats.  cfg2 = qft_n18 on the 4x4
-    mesh (256 repeats), cfg3 = qft_n63 on the 8x8 torus (64 repeats).  With more than one rank the repeats are
+    batches of whole placements + their costs, as the driver runs a config's repeats.  cfg1 = the 256-qubit QFT of
+    example_config.txt on its 2x1 mesh (3 repeats, as shipped), cfg2 = qft_n18 on the 4x4 mesh (256 repeats), cfg3 =
+    qft_n63 on the 8x8 torus (64 repeats).  The repeats of HQA / TRHQA / GTRHQA are identical computations (the
+    reference's own loop runs the same deterministic placement `repeats` times, main.py:88-92); every one of them is
+    computed here, none is reused, and the rows say so (identical_repeats).  With more than one rank the repeats are
     dealt round-robin to the ranks, as the driver deals them, and the per-placer sums and minima go through the
     driver's final reduction (one SUM and one MIN all-reduce of a few doubles): every rank ends with the job's
     mean and min cost."""
@@ -162,7 +229,7 @@ def bench_shipped(dev, rank=0, world=1):
     from quantum_simulator_amd.placers import PLACERS
     rows = []
     names = ("HQA", "TRHQA", "GTRHQA", "BFS", "RANDOM")
-    for cfg, name, B in (("cfg2", "qft18_mesh4x4_u", 256), ("cfg3", "qft63_torus8x8_u", 64)):
+    for cfg, name, B in (("cfg1", "gen256_mesh2x1_u", 3), ("cfg2", "qft18_mesh4x4_u", 256), ("cfg3", "qft63_torus8x8_u", 64)):
         gc = load_case(name)
         circ, arch = case_circuit(gc), case_arch(gc)
         mine = len([r for r in range(B) if r % world == rank])
@@ -193,6 +260,7 @@ def bench_shipped(dev, rank=0, world=1):
             w = float(wall[pi].item())
             rows.append({"config": cfg, "case": name, "placer": pname, "repeats": B, "ranks": world, "slices": gc.T,
                          "seconds": w, "slice_steps_per_s": B * gc.T / w,
+                         "identical_repeats": pname in ("HQA", "TRHQA", "GTRHQA"),
                          "mean_cost": float(sums[0, pi, 0] / sums[0, pi, 1]) if sums[0, pi, 1] else math.inf,
                          "min_cost": float(mins[0, pi]), "finite_repeats": int(sums[0, pi, 1]),
                          "reduce_ms": reduce_ms if world > 1 else None})
@@ -586,7 +654,8 @@ def main():
     if not args.no_qubo:
         del A
         torch.cuda.empty_cache()
-        qubo = bench_qubo(torch, dev, rank, args.qubo_sweeps, args.qubo_replicas)
+        qubo = bench_qubo(torch, dev, rank, args.qubo_sweeps, args.qubo_replicas,
+                          cpu_seconds=args.cpu_seconds / 2 if (world == 1 and not args.no_cpu) else 0.0)
         if world > 1:
             fl = torch.tensor([qubo["spin_flip_attempts_per_s"]], dtype=torch.float64, device=dev)
             dist.all_reduce(fl, op=dist.ReduceOp.SUM)

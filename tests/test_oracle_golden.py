@@ -340,3 +340,34 @@ def test_qubo_cost_and_comm_matrix_restatements_match_reference_fixture(name):
             got = np.array(O.comm_matrix(gc.slices, gc.gate_q, gc.gate_mr, rows, gc.C))
             assert (got == _comm_from_upper(entry["comm_upper"], gc.C)).all(), pname
             assert int(got.sum()) == entry["comm_total"]
+
+
+def test_sparse_qubo_model_and_cpu_annealer():
+    """oracle.qubo_cpu (the CPU baseline of the QUBO path): its sparse form of the objective equals
+    placer_oracle.qubo_energy (Qubo_placer.py:84-133 term by term) on random states, and the C annealer's summed
+    energy changes equal the energy difference between its final and initial state."""
+    from oracle import qubo_cpu
+    from quantum_simulator_amd import layered_gate_arrays
+    from quantum_simulator_amd.timeslices import CircuitIR
+    rng = np.random.default_rng(5)
+    for Q, T, C, cap in ((6, 3, 4, 3), (9, 4, 3, 4), (12, 2, 5, 2)):
+        q0, q1, _ = layered_gate_arrays(Q, T, 0.6, seed=Q + T)
+        keep = rng.random(len(q0)) > 0.25
+        ir = CircuitIR.from_gate_tables(Q, q0[keep], q1[keep])
+        names = [f"q[{i}]" for i in range(Q)]
+        act, inter = O.qubo_slices(ir.slices, ir.gate_q, names)
+        H = rng.integers(1, 5, size=(C, C))
+        H = np.triu(H, 1)
+        H = H + H.T
+        sm = qubo_cpu.SparseModel(act, inter, C, cap, H)
+        assert sm.N == sum(C * (len(a) + cap) for a in act)
+        for _ in range(6):
+            s = rng.integers(0, 2, size=sm.N).astype(np.int8)
+            x = [[[int(s[sm.var_x(t, j, i)]) for i in range(len(act[t]))] for j in range(C)] for t in range(len(act))]
+            y = [[[int(s[sm.var_y(t, j, p)]) for p in range(cap)] for j in range(C)] for t in range(len(act))]
+            assert sm.energy(s) == O.qubo_energy(act, inter, C, cap, H.tolist(), x, y)
+        s = rng.integers(0, 2, size=sm.N).astype(np.int8)
+        e0 = sm.energy(s)
+        dE, accepted = sm.anneal(s, 50, 0.01, 1.2, seed=7)
+        assert accepted > 0 and sm.energy(s) == e0 + dE
+        assert sm.energy(s) <= e0
