@@ -324,7 +324,11 @@ int qp_slice_cost_v3_multi(const QpCircuit* circ, const double* tables, int32_t 
  * and frees nothing.  A batch that needs more scratch (about one double per partition and chunk of 16..256
  * slices, plus 256 KB for an fp64 table of more than 134 cores) is refused with QP_ENOSPC: split it, or use
  * qp_slice_cost_v3.  Calls on one GPU share that GPU's array: two of them in flight at once on different
- * streams race (calls on one stream are ordered and safe; nothing has to be cleared between calls). */
+ * streams race (calls on one stream are ordered and safe; nothing has to be cleared between calls).
+ * Under stream capture: make one ordinary call on the device first (it looks up the scratch array's address, which may
+ * load the code object, and sets the kernels' shared-memory attributes); after that the call only queries occupancy and
+ * enqueues kernels, and a captured graph of it can be replayed on new contents of A (tests/test_zz_no_alloc.py does so).
+ * Which kernel runs depends on the circuit, the table and the batch only, so it is the one qp_slice_cost_v3 runs. */
 #define QP_STATIC_SCRATCH_BYTES (4u << 20)
 size_t qp_static_scratch_bytes(void);
 int qp_slice_cost_v3_static(const QpCircuit* circ, const QpDTable* dt, const uint8_t* A, int64_t B, int32_t Tp,

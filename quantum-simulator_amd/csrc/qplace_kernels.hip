@@ -2738,19 +2738,25 @@ namespace {
 
 // The dense cost path behind qp_slice_cost_v3 and qp_slice_cost_v3_static: every launch of it, with the
 // partial sums (and the symmetrised triangle of a large fp64 table) in `workspace`.
-int slice_cost_v3_impl(const QpCircuit* circ, const QpDTable* dt, const uint8_t* A, int64_t B, int32_t Tp,
+// Which kernel runs depends on the circuit, the table and the batch only, never on how much workspace there is: a
+// workspace too small for the chosen kernel is QP_ENOSPC (so both entry points give the same bits or an error).
+int slice_cost_v3_impl(const char* fn, const QpCircuit* circ, const QpDTable* dt, const uint8_t* A, int64_t B, int32_t Tp,
                        int32_t ldq, double* out, void* workspace, size_t workspace_bytes, void* stream_) {
-    if (int rc = check_common("qp_slice_cost_v3", circ, dt, A, B, Tp, ldq, out)) return rc;
+    if (int rc = check_common(fn, circ, dt, A, B, Tp, ldq, out)) return rc;
+    auto need_workspace = [&](size_t need) -> int {
+        if (workspace && workspace_bytes >= need) return QP_OK;
+        return qp::fail(QP_ENOSPC, "%s: this batch needs %zu bytes of scratch, %zu given", fn, need, workspace ? workspace_bytes : (size_t)0);
+    };
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int32_t T = circ->T;
-    if (Tp < T) return qp::fail(QP_EINVAL, "qp_slice_cost_v3: partition has %d rows, circuit has %d slices", Tp, T);
+    if (Tp < T) return qp::fail(QP_EINVAL, "%s: partition has %d rows, circuit has %d slices", fn, Tp, T);
     if (T == 0) {
         k_fill<<<(unsigned)((B + 255) / 256), 256, 0, stream>>>(out, B, 0.0);
         HIP_TRY(hipGetLastError());
         return QP_OK;
     }
     if (!circ->slice_edge_ptr || (circ->nE > 0 && !circ->edges))
-        return qp::fail(QP_EINVAL, "qp_slice_cost_v3: circuit edge tables missing");
+        return qp::fail(QP_EINVAL, "%s: circuit edge tables missing", fn);
 
     V3Args p{};
     p.A = A;
@@ -2786,7 +2792,7 @@ int slice_cost_v3_impl(const QpCircuit* circ, const QpDTable* dt, const uint8_t*
     bool wide_two = false, wide_pairs = false;
     double* wide_fold = nullptr;
     if (!narrow) {
-        if (ldq / 16 > kWidePieces * kV3Threads) return qp::fail(QP_EINVAL, "qp_slice_cost_v3: rows longer than 65536 bytes");
+        if (ldq / 16 > kWidePieces * kV3Threads) return qp::fail(QP_EINVAL, "%s: rows longer than 65536 bytes", fn);
         const bool gridpath = has_grid_form(dt);
         // the table (if it fits beside one set of strips) and one or two strips of a row per group
         wide_strips = (size_t)kV3Threads * 16 * (ldq / 16 <= kV3Threads ? 1 : kWidePieces);
@@ -2812,7 +2818,8 @@ int slice_cost_v3_impl(const QpCircuit* circ, const QpDTable* dt, const uint8_t*
             const int rows = (int)std::min<int64_t>(T, std::max<int64_t>(32 * (kV3Threads / P1), want));
             const int64_t items = (int64_t)((T + rows - 1) / rows) * B;
             const size_t part_bytes = ((size_t)items * sizeof(double) + 255) & ~(size_t)255;
-            if (workspace && workspace_bytes >= part_bytes + (size_t)kPairSlots * sizeof(double)) {
+            if (int rc = need_workspace(part_bytes + (size_t)kPairSlots * sizeof(double))) return rc;
+            {
                 wide_pairs = true;
                 wide_fold = reinterpret_cast<double*>(static_cast<uint8_t*>(workspace) + part_bytes);
                 wide_threads = kV3Threads;
@@ -2824,9 +2831,7 @@ int slice_cost_v3_impl(const QpCircuit* circ, const QpDTable* dt, const uint8_t*
     }
     const int32_t nchunks = (T + p.rows_per_item - 1) / p.rows_per_item;
     p.nitems = (int64_t)nchunks * B;
-    if (!workspace || workspace_bytes < (size_t)p.nitems * sizeof(double))
-        return qp::fail(QP_ENOSPC, "qp_slice_cost_v3: workspace needs %zu bytes", (size_t)p.nitems * sizeof(double));
-    p.partial = static_cast<double*>(workspace);
+    p.partial = static_cast<double*>(workspace);  // every path checks its own need before it launches
 
     // Rows of 513 to 1024 bytes and a 16-bit table of at most 16 cores without a closed form: one slice per step, so
     // the per-slice gate list is the grouped list, and the kernel for short rows brings its table form whose
@@ -2868,7 +2873,8 @@ int slice_cost_v3_impl(const QpCircuit* circ, const QpDTable* dt, const uint8_t*
             c.nitems = (int64_t)cchunks * B;
             const size_t part_bytes = ((size_t)c.nitems * sizeof(double) + 255) & ~(size_t)255;
             const size_t clds = (size_t)kPairSlots * sizeof(uint32_t) + gstrips + kV3Waves * sizeof(double);
-            if (clds <= (size_t)kLdsBytes && workspace_bytes >= part_bytes + (size_t)kPairSlots * sizeof(double)) {
+            if (clds <= (size_t)kLdsBytes) {
+                if (int rc = need_workspace(part_bytes + (size_t)kPairSlots * sizeof(double))) return rc;
                 double* fold = reinterpret_cast<double*>(static_cast<uint8_t*>(workspace) + part_bytes);
                 k_sym_fold<<<kPairSlots / 256, 256, 0, stream>>>(static_cast<const double*>(dt->table), dt->C, fold);
                 HIP_TRY(hipGetLastError());
@@ -2882,7 +2888,8 @@ int slice_cost_v3_impl(const QpCircuit* circ, const QpDTable* dt, const uint8_t*
                 return QP_OK;
             }
         }
-        if (workspace_bytes >= (size_t)gchunks * B * sizeof(double)) {
+        {
+            if (int rc = need_workspace((size_t)gchunks * B * sizeof(double))) return rc;
             const bool gridpath = has_grid_form(dt);
             const size_t strips = gstrips;
             const size_t tab256 = (size_t)dt->C * 256 * esz;
@@ -2962,6 +2969,7 @@ int slice_cost_v3_impl(const QpCircuit* circ, const QpDTable* dt, const uint8_t*
         void (*kern)(V3Args) = nullptr;
         if (gridpath) {
             // closed-form distances: no table in LDS, so more than one workgroup fits a CU
+            if (int rc = need_workspace((size_t)p.nitems * sizeof(double))) return rc;
             if (int rc = fill_grid_args(p, dt)) return rc;
             const QpGridMetric& g = dt->grid;
             const bool wrap = g.wrap_x || g.wrap_y;
@@ -2988,7 +2996,8 @@ int slice_cost_v3_impl(const QpCircuit* circ, const QpDTable* dt, const uint8_t*
             const int32_t pchunks = (T + q.rows_per_item - 1) / q.rows_per_item;
             q.nitems = (int64_t)pchunks * B;
             const size_t part_bytes = ((size_t)q.nitems * sizeof(double) + 255) & ~(size_t)255;
-            if (pairs_lds <= (size_t)kLdsBytes && workspace_bytes >= part_bytes + fold_bytes) {
+            if (pairs_lds <= (size_t)kLdsBytes) {
+                if (int rc = need_workspace(part_bytes + fold_bytes)) return rc;
                 double* fold = reinterpret_cast<double*>(static_cast<uint8_t*>(workspace) + part_bytes);
                 k_sym_fold<<<kPairSlots / 256, 256, 0, stream>>>(static_cast<const double*>(dt->table), dt->C, fold);
                 HIP_TRY(hipGetLastError());
@@ -3008,8 +3017,7 @@ int slice_cost_v3_impl(const QpCircuit* circ, const QpDTable* dt, const uint8_t*
             int band_rows = 1;  // largest power of two whose band fits beside the strips
             while ((size_t)band_rows * 2 * 256 * esz + 16 + strips <= (size_t)kLdsBytes) band_rows *= 2;
             const int passes = (dt->C + band_rows - 1) / band_rows;
-            if (workspace_bytes < (size_t)passes * p.nitems * sizeof(double))
-                return qp::fail(QP_ENOSPC, "qp_slice_cost_v3: workspace needs %zu bytes", (size_t)passes * p.nitems * sizeof(double));
+            if (int rc = need_workspace((size_t)passes * p.nitems * sizeof(double))) return rc;
             kern = k_cost_v3_row<QP_DT_F64, kTabLdsBand>;
             const size_t band_lds = strips + (((size_t)band_rows * 256 + 1) * esz + 15) / 16 * 16;
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)band_lds));
@@ -3034,7 +3042,8 @@ int slice_cost_v3_impl(const QpCircuit* circ, const QpDTable* dt, const uint8_t*
             q.rows_per_item = (int)std::min<int64_t>(T, std::min<int64_t>(256, std::max<int64_t>(32, want)));
             const int32_t qchunks = (T + q.rows_per_item - 1) / q.rows_per_item;
             q.nitems = (int64_t)qchunks * ngroups;
-            if (workspace_bytes >= (size_t)qchunks * B * sizeof(double)) {
+            {
+                if (int rc = need_workspace((size_t)qchunks * B * sizeof(double))) return rc;
                 kern = dt->kind == QP_DT_F64 ? k_cost_v3_row4<QP_DT_F64, kV3Ahead> : k_cost_v3_row4<QP_DT_U16, kV3Ahead>;
                 const size_t lds4 = tab256 + (size_t)kRow4Waves * kRow4Strip;
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
@@ -3060,6 +3069,7 @@ int slice_cost_v3_impl(const QpCircuit* circ, const QpDTable* dt, const uint8_t*
             kern = mode == kTabLds256 ? k_cost_v3<QP_DT_U16, kTabLds256>
                  : mode == kTabLdsC   ? k_cost_v3<QP_DT_U16, kTabLdsC> : k_cost_v3<QP_DT_U16, kTabGlobal>;
         }
+        if (int rc = need_workspace((size_t)p.nitems * sizeof(double))) return rc;
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         kern<<<grid, kV3Threads, lds, stream>>>(p);
     } else {
@@ -3086,6 +3096,7 @@ int slice_cost_v3_impl(const QpCircuit* circ, const QpDTable* dt, const uint8_t*
             kern = tab_lds ? QP_WIDE(QP_DT_U16, kTabLdsC) : QP_WIDE(QP_DT_U16, kTabGlobal);
         }
 #undef QP_WIDE
+        if (int rc = need_workspace((size_t)p.nitems * sizeof(double))) return rc;
         const size_t lds = (wide_pairs ? (size_t)kPairSlots * sizeof(uint32_t) : wide_tab) + (two ? 2 : 1) * wide_strips;
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int per_cu = 1;
@@ -3219,7 +3230,7 @@ int qp::comm_matrix_pairs(const QpCircuit* circ, const uint8_t* A, int64_t B, in
 
 extern "C" int qp_slice_cost_v3(const QpCircuit* circ, const QpDTable* dt, const uint8_t* A, int64_t B, int32_t Tp,
                                 int32_t ldq, double* out, void* workspace, size_t workspace_bytes, void* stream) {
-    return slice_cost_v3_impl(circ, dt, A, B, Tp, ldq, out, workspace, workspace_bytes, stream);
+    return slice_cost_v3_impl("qp_slice_cost_v3", circ, dt, A, B, Tp, ldq, out, workspace, workspace_bytes, stream);
 }
 
 extern "C" size_t qp_static_scratch_bytes(void) { return kStaticScratchBytes; }
@@ -3228,7 +3239,7 @@ extern "C" int qp_slice_cost_v3_static(const QpCircuit* circ, const QpDTable* dt
                                        int32_t Tp, int32_t ldq, double* out, void* stream) {
     void* ws = nullptr;
     if (int rc = static_scratch(&ws)) return rc;
-    const int rc = slice_cost_v3_impl(circ, dt, A, B, Tp, ldq, out, ws, kStaticScratchBytes, stream);
+    const int rc = slice_cost_v3_impl("qp_slice_cost_v3_static", circ, dt, A, B, Tp, ldq, out, ws, kStaticScratchBytes, stream);
     if (rc == QP_ENOSPC)
         return qp::fail(QP_ENOSPC,
                         "qp_slice_cost_v3_static: %lld partitions x %d slices need more than the %zu bytes of static "
@@ -3648,8 +3659,8 @@ __global__ __launch_bounds__(kMultiThreads) void k_cost_v3_multi(V3MultiArgs p) 
     for (int64_t b = blockIdx.x; b < p.B; b += gridDim.x) {
         const int32_t ti = min(max(p.tab[b], 0), p.S - 1);
         const double* tab = p.tables + (size_t)ti * C * C;
+        __syncthreads();  // the previous instance's look-ups are done and thread 0 has read its partial sums
         if constexpr (TAB_LDS) {
-            __syncthreads();  // the previous instance's look-ups are done
             double* dst = reinterpret_cast<double*>(smem);
             for (uint32_t k = threadIdx.x; k <= last; k += kMultiThreads) dst[k] = tab[k];
             __syncthreads();

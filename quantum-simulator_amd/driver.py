@@ -25,7 +25,6 @@ import csv
 import math
 import os
 import random
-import re
 import time
 import zlib
 
@@ -36,23 +35,25 @@ REQUIRED = ["mode", "topology", "num_cores_x", "num_cores_y", "ncm_qubits", "ncp
             "circuit_folders", "placers", "repeats", "out_csv", "plot_file"]
 
 
-_NUMBER = re.compile(r"[+-]?(\d+(\.\d*)?|\.\d+)([eE][+-]?\d+)?$")
 
 
 def _scalar_or_list(text: str):
-    """A config value: an int when it reads as one, else a comma list (all floats when every item is a
-    number, a single float for a one-item list, otherwise the stripped strings), else the string."""
+    """A config value as config_parser.py:4-17 reads it: whatever ``int()`` accepts is an int; otherwise a value
+    with a comma is the list of its non-empty items, as floats when ``float()`` accepts every one of them (a
+    single item then stands alone); anything else stays a string."""
     text = text.strip()
-    if re.fullmatch(r"[+-]?\d+", text):
+    try:
         return int(text)
+    except ValueError:
+        pass
     if "," not in text:
         return text
-    items = [piece.strip() for piece in text.split(",")]
-    items = [piece for piece in items if piece]
-    if not all(_NUMBER.match(piece) or piece.lower() in ("inf", "nan", "+inf", "-inf", "infinity") for piece in items):
+    items = [piece for piece in (part.strip() for part in text.split(",")) if piece]
+    try:
+        numbers = [float(piece) for piece in items]
+        return numbers if len(numbers) > 1 else numbers[0]
+    except (ValueError, IndexError):
         return items
-    numbers = [float(piece) for piece in items]
-    return numbers[0] if len(numbers) == 1 else numbers
 
 
 def _as_name_list(value):
@@ -61,8 +62,9 @@ def _as_name_list(value):
 
 
 def parse_config_file(path: str) -> dict:
-    """config_parser.py:20-84: same keys, same checks in the same order (mode and topology first, then the
-    rest), same normalisation of the weight range, the folder list and the placer list."""
+    """config_parser.py:20-84: same keys, same checks in the same order (mode: present, then its value; topology:
+    present, then its value; then the rest), same normalisation of the weight range, the folder list (with the
+    warning for a folder that does not exist) and the placer list."""
     if not os.path.exists(path):
         raise AssertionError(f"Config file not found: {path}")
     cfg = {}
@@ -74,18 +76,19 @@ def parse_config_file(path: str) -> dict:
                 cfg[key.strip()] = _scalar_or_list(value)
     checks = {"mode": (["simulate"], "mode must be 'simulate' or ..."),
               "topology": (TOPOLOGY_NAMES, "Invalid topology, must be one of " + ", ".join(TOPOLOGY_NAMES))}
-    for position, key in enumerate(REQUIRED):
-        if position == len(checks):  # the two checked keys come first in REQUIRED
-            for name, (allowed, message) in checks.items():
-                if cfg[name] not in allowed:
-                    raise AssertionError(message)
+    for key in REQUIRED:  # presence, and for mode and topology the value, key by key (config_parser.py:35-52)
         if key not in cfg:
             raise AssertionError(f"Missing required parameter: {key}")
+        if key in checks and cfg[key] not in checks[key][0]:
+            raise AssertionError(checks[key][1])
     span = cfg["edge_weight_range"]
     if not (isinstance(span, list) and len(span) >= 2):
         raise AssertionError("edge_weight_range must be two numbers separated by a comma, e.g. 1.0,10.0")
     cfg["edge_weight_range"] = (float(span[0]), float(span[1]))
     cfg["circuit_folders"] = [os.path.expanduser(name) for name in _as_name_list(cfg["circuit_folders"])]
+    for folder in cfg["circuit_folders"]:
+        if not os.path.isdir(folder):
+            print(f"Warning: circuit folder does not exist: {folder}")
     cfg["placers"] = _as_name_list(cfg["placers"])
     return cfg
 

@@ -57,6 +57,28 @@ def test_bad_values(tmp_path):
         driver.parse_config_file(str(p))
 
 
+def test_checks_come_in_the_reference_order(tmp_path, capsys):
+    """config_parser.py:35-39 tests mode's value before it looks for topology: a config with a bad mode and no
+    topology complains about the mode.  Values are read as config_parser.py:4-17 reads them: whatever int() and
+    float() accept.  A circuit folder that does not exist is warned about, not refused (config_parser.py:70-72)."""
+    p = tmp_path / "cfg.txt"
+    lines = [l for l in EXAMPLE.splitlines() if not l.startswith("topology")]
+    p.write_text("\n".join(lines).replace("mode = simulate", "mode = dream"))
+    with pytest.raises(AssertionError, match="mode must be"):
+        driver.parse_config_file(str(p))
+    p.write_text("\n".join(lines))
+    with pytest.raises(AssertionError, match="Missing required parameter: topology"):
+        driver.parse_config_file(str(p))
+    assert driver._scalar_or_list(" 1_000 ") == 1000 and driver._scalar_or_list("+7") == 7
+    assert driver._scalar_or_list("1e3, -infinity") == [1000.0, float("-inf")]
+    assert driver._scalar_or_list("2.5,") == 2.5 and driver._scalar_or_list("a, 2") == ["a", "2"]
+    assert driver._scalar_or_list(",") == [] and driver._scalar_or_list("2.5") == "2.5"
+    p.write_text(EXAMPLE.replace("circuits/gen", str(tmp_path / "nowhere")))
+    cfg = driver.parse_config_file(str(p))
+    assert cfg["circuit_folders"] == [str(tmp_path / "nowhere")]
+    assert "Warning: circuit folder does not exist" in capsys.readouterr().out
+
+
 def test_complete_topology_falls_back_to_4x4_all_to_all(capsys):
     # the parser accepts "complete", the topology builder does not: the driver's fall-back machine
     arch = driver.build_arch({"topology": "complete", "num_cores_x": 3, "num_cores_y": 3, "ncm_qubits": 4,

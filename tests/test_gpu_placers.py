@@ -657,6 +657,43 @@ def test_cost_v3_with_a_table_per_partition(Q, T, C, S):
         assert (np.isinf(one) and np.isinf(got[b])) or abs(one - got[b]) <= 1e-12 * max(1.0, abs(one))
 
 
+def test_cost_v3_with_a_table_per_partition_more_partitions_than_workgroups():
+    """Tables of more than 128 cores are read from device memory by workgroups that each walk several
+    partitions (the grid is capped at eight workgroups per compute unit): 2600 partitions on 130 cores, every
+    result against a NumPy evaluation of the same sums, and two launches bit for bit the same."""
+    import torch
+    from quantum_simulator_amd import engine, layered_gate_arrays
+    from quantum_simulator_amd.timeslices import CircuitIR
+    dev = torch.device("cuda", 0)
+    Q, T, C, S, B = 48, 6, 130, 3, 2600
+    rng = np.random.default_rng(77)
+    q0, q1, _ = layered_gate_arrays(Q, T, 0.5, seed=3)
+    ir = CircuitIR.from_gate_tables(Q, q0, q1)
+    eu = list(range(C - 1))
+    ev = [i + 1 for i in range(C - 1)]
+    W = rng.uniform(1, 3, size=(S, len(eu)))
+    tables = engine.apsp_batch(C, eu, ev, W)
+    dc, eng = engine.DeviceCircuit(ir, dev), engine.Engine(dev)
+    tab = rng.integers(0, S, size=B).astype(np.int32)
+    A = rng.integers(0, C, size=(B, ir.T, dc.ldq), dtype=np.uint8)
+    Ad, d_tab, d_tables = torch.from_numpy(A).to(dev), torch.from_numpy(tab).to(dev), torch.from_numpy(tables).to(dev)
+    got = eng.cost_v3_multi(dc, d_tables, d_tab, Ad).cpu().numpy()
+    assert got.tobytes() == eng.cost_v3_multi(dc, d_tables, d_tab, Ad).cpu().numpy().tobytes()
+    # the same sums with NumPy gathers
+    want = np.zeros(B)
+    Dz = tables.copy()
+    Dz[:, np.arange(C), np.arange(C)] = 0.0
+    Al = A[:, :, :Q].astype(np.int64)
+    for t in range(ir.T):
+        ops = ir.slice_ops(t)
+        if ops:
+            u = np.array([o[1] for o in ops]); v = np.array([o[2] for o in ops])
+            want += Dz[tab[:, None], Al[:, t][:, u], Al[:, t][:, v]].sum(axis=1)
+        if t >= 2:
+            want += Dz[tab[:, None], Al[:, t - 1], Al[:, t]].sum(axis=1)
+    assert np.allclose(got, want, rtol=1e-12, atol=0)
+
+
 @pytest.mark.parametrize("pname", ["HQA", "TRHQA"])
 def test_place_batch_with_a_table_per_instance(pname):
     """A placement batch in which every instance has its own damaged network equals the placements made one

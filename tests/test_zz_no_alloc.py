@@ -62,11 +62,10 @@ def test_static_entry_point_refuses_what_does_not_fit():
     from quantum_simulator_amd._lib import QplaceError, lib
     dev = torch.device("cuda", 0)
     eng = engine.Engine(dev)
-    # 40 qubits: rows of 48 bytes go 21 to a wave step and 84 to a chunk, one partial sum per partition and
-    # chunk; enough partitions that the sums outgrow the 4 MiB the library holds
-    dc, dt, _ = _setup(torch, engine, dev, 40, 900, 8, 1, True, seed=5)
-    nchunks = (dc.ir.T + 83) // 84
-    B = (4 << 20) // 8 // nchunks + 1000
+    # the kernel for this shape (rows of 48 bytes, a whole partition per item) keeps one partial sum per
+    # partition: more partitions than the 4 MiB the library holds has doubles
+    dc, dt, _ = _setup(torch, engine, dev, 40, 5, 8, 1, True, seed=5)
+    B = (4 << 20) // 8 + 1000
     A = torch.zeros((B, dc.ir.T, dc.ldq), dtype=torch.uint8, device=dev)
     out = torch.empty(B, dtype=torch.float64, device=dev)
     with pytest.raises(QplaceError) as err:
@@ -75,3 +74,40 @@ def test_static_entry_point_refuses_what_does_not_fit():
     # the same batch in two halves fits
     half = eng.cost_v3_static(dc, dt, A[:B // 2], out[:B // 2]).cpu().numpy()
     assert (half == 0.0).all()
+    # and what the workspace entry point computes for a shape does not depend on how much workspace it is given:
+    # with too little it refuses, it never takes another kernel (whose rounding could differ)
+    dc2, dt2, A2 = _setup(torch, engine, dev, 1024, 20, 256, 4, False, seed=9)
+    want = eng.cost_v3(dc2, dt2, A2).cpu().numpy()
+    small = torch.empty(1024, dtype=torch.uint8, device=dev)
+    rc = lib().qp_slice_cost_v3(C.byref(dc2.c), C.byref(dt2.packed), A2.data_ptr(), 4, A2.shape[1], A2.shape[2],
+                                out.data_ptr(), small.data_ptr(), small.numel(), None)
+    torch.cuda.synchronize(dev)
+    assert rc == -3
+    again = torch.empty(4, dtype=torch.float64, device=dev)
+    assert eng.cost_v3_static(dc2, dt2, A2, again).cpu().numpy().tobytes() == want.tobytes()
+
+
+def test_static_entry_point_inside_a_captured_graph():
+    """After one ordinary call (which resolves the scratch address and the kernels' attributes), the entry point is
+    recorded into a HIP graph and replayed on new inputs: nothing in it allocates or synchronises."""
+    import torch
+    from quantum_simulator_amd import engine
+    dev = torch.device("cuda", 0)
+    eng = engine.Engine(dev)
+    for Q, T, ncores, B, integer in ((1024, 30, 256, 6, False), (63, 50, 64, 16, False), (1024, 12, 256, 5, True)):
+        dc, dt, A = _setup(torch, engine, dev, Q, T, ncores, B, integer, seed=Q + T)
+        out = torch.full((B,), -1.0, dtype=torch.float64, device=dev)
+        eng.cost_v3_static(dc, dt, A, out)  # warm-up outside the capture
+        want0 = eng.cost_v3(dc, dt, A).cpu().numpy()
+        assert out.cpu().numpy().tobytes() == want0.tobytes()
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            eng.cost_v3_static(dc, dt, A, out)
+        for rep in range(2):
+            A.copy_(torch.randint(0, ncores, A.shape, device=dev, dtype=torch.int16).to(torch.uint8))
+            out.fill_(-1.0)
+            g.replay()
+            torch.cuda.synchronize(dev)
+            want = eng.cost_v3(dc, dt, A).cpu().numpy()
+            assert out.cpu().numpy().tobytes() == want.tobytes(), (Q, rep)
