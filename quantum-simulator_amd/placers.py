@@ -315,11 +315,16 @@ class _HqaFamily(BasePlacer):
             raise ValueError(f"Not enough space: {Q} qubits need {C * cap} total slots")
 
     def place_per_timeslice(self, circuit, multicore_arch):
+        """HQA_placer.py:20-176 / TRHQA_placer.py:22-228: one placement, through the native loop of the batches
+        (one lane): per slice one device cost-matrix launch and one host assignment solve per while-iteration."""
         ctx = self._context(circuit, multicore_arch)
-        return ctx.rows_to_partition(self.place_rows(ctx, multicore_arch.qpu_qubit_num))
+        rows = self.place_batch(circuit, multicore_arch, B=1, threads=1)[0]
+        return ctx.rows_to_partition([rows[t] for t in range(rows.shape[0])])
 
     def place_rows(self, ctx: _Context, cap: int):
-        """HQA_placer.py:56-176 / TRHQA_placer.py:62-228 on index arrays.  Returns T uint8 rows."""
+        """HQA_placer.py:56-176 / TRHQA_placer.py:62-228 on index arrays, slice by slice in Python around
+        ``Engine.cost_matrix`` and ``lsap``: the readable form of the loop, which the tests hold the native one
+        against (about ten times slower).  Returns T uint8 rows."""
         ir, C = ctx.ir, ctx.arch.C
         Q, T = ir.Q, ir.T
         self._check_capacity(Q, C, cap)

@@ -38,6 +38,10 @@ def test_hqa_family_place_and_cost(name, pname):
     cost = placer.per_timeslice_cost(circ, part, arch)
     assert _cost_ok(cost, gc.cost(pname), name.endswith("_i"), ctx.ir.nE + ctx.ir.T * gc.Q)
     assert placer._dist_matrix.tobytes() == gc.D.tobytes()
+    if pname != "GTRHQA" and gc.T <= 200:
+        # the slice-by-slice Python form of the same loop (one cost-matrix call and one solve per iteration)
+        rows = np.array(placer.place_rows(ctx, arch.qpu_qubit_num))
+        assert (rows == gc.part(pname)).all(), "place_rows differs from the reference's partition"
 
 
 @pytest.mark.parametrize("name", MEDIUM)
