@@ -698,10 +698,10 @@ def main():
             "shipped_circuits": shipped, "shipped_circuits_cost_at_scale": shipped_cost, "broken_links": broken,
         }
         # HBM bytes per launch as measured with rocprofv3 PMC counters in a separate run of this workload
-        # (profiles/r02_traffic.json, one entry per kernel name; FETCH_SIZE doubled as gfx950 requires for
+        # (profiles/r03_traffic.json, one entry per kernel name; FETCH_SIZE doubled as gfx950 requires for
         # 16-byte-per-lane streams).  An entry is used only for the kernel and the workload it was measured on.
         try:
-            with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r03_traffic.json")) as f:
                 measured = json.load(f)
         except (OSError, ValueError):
             measured = {}

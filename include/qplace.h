@@ -420,8 +420,9 @@ int qp_hqa_place_batch_multi(int32_t kind, const QpCircuit* circ, const double* 
  * initial: dev uint8 [B][ldq] core index per qubit (< C; row 0 of every instance).  out: dev uint8
  * [B][T+1][ldq]; row 0 is a copy of initial (pad columns included), the rest follow.
  * dt must be QP_DT_F64.  The caller checks what the reference checks before it starts (capacity).
- * workspace: dev, qp_gtrhqa_workspace(C) bytes, 8-byte aligned (prepared copies of the table: fp64, and 16-bit
- * for tables of small integers, which the call detects itself). */
+ * workspace: dev, qp_gtrhqa_workspace(C) bytes, 16-byte aligned (prepared copies of the table: fp64, and 16-bit
+ * for tables of small integers, which the call detects itself; and for every pair of source cores the sixteen
+ * cheapest cores of an op whose qubits sit on them, in bidding order, which most bids are read from). */
 size_t qp_gtrhqa_workspace(int32_t C);
 int qp_gtrhqa_place(const QpCircuit* circ, const QpDTable* dt, const uint8_t* initial, int64_t B, int32_t ldq,
                     int32_t cap, uint8_t* out, void* workspace, size_t workspace_bytes, void* stream);

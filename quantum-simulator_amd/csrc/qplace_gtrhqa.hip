@@ -36,12 +36,13 @@ struct GpArgs {
     const double* D;            // prepared copy (row 0 and diagonal zero)
     const uint16_t* D16;        // the same as 16-bit integers; only meaningful when flags[1] is set
     const int32_t* all_finite;  // [0] 1 when every distance is finite, [1] 1 when every distance is an integer <= 32767
+    const uint8_t* shortlist;   // [C][C][kShort]: the cheapest cores of every pair of source cores, see k_gtrhqa_shortlist
     const uint8_t* initial;
     uint8_t* out;
     int64_t B;
     int32_t T, Q, ldq, C, cap, max_ops;
     // byte offsets into dynamic LDS
-    uint32_t off_rows, off_occ, off_best, off_win, off_bid, off_target, off_uv, off_a12, off_flags, off_cores, off_need;
+    uint32_t off_rows, off_occ, off_best, off_win, off_bid, off_target, off_uv, off_a12, off_flags, off_cores, off_need, off_scan;
 };
 
 struct OpFlags {
@@ -148,6 +149,52 @@ __global__ void k_gtrhqa_prepare(const double* D, int C, double* Dz, uint16_t* D
     }
 }
 
+// The cheapest cores of an op, before anything is known about a slice: for every pair (a1, a2) of source cores the
+// kShort cores c with the smallest entry Dz[a1][c] + Dz[a2][c], ascending by (entry, core) -- the order in which an op
+// whose qubits sit on a1 and a2 would bid for cores if all of them were free.  The first core of that list that is free
+// in a slice is therefore exactly the op's first minimum over the free cores, whenever the list holds a free core at
+// all; only an op whose kShort best cores are all gone has to scan the table.  One thread per pair, an insertion into
+// a sorted array per core; built once per call (the table is fixed for all slices of all instances).  0xFF = no core
+// (fewer than kShort cores).
+constexpr int kShort = 16;
+
+__global__ __launch_bounds__(256) void k_gtrhqa_shortlist(const double* Dz, int C, uint8_t* out) {
+    const int pair = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pair >= C * C) return;
+    const int a1 = pair / C, a2 = pair - a1 * C;
+    unsigned long long key[kShort];
+    uint32_t core[kShort];
+#pragma unroll
+    for (int j = 0; j < kShort; ++j) {
+        key[j] = ~0ull;
+        core[j] = 0xFFu;
+    }
+    const double* r1 = Dz + (size_t)a1 * kPitch;
+    const double* r2 = Dz + (size_t)a2 * kPitch;
+    for (int c = 0; c < C; ++c) {
+        unsigned long long k = dbits(r1[c] + r2[c]);
+        uint32_t id = (uint32_t)c;
+        if (k >= key[kShort - 1]) continue;  // cores come in ascending order: an equal entry stays behind
+        bool moved = false;  // from the slot the core goes into, every later slot takes its predecessor
+#pragma unroll
+        for (int j = 0; j < kShort; ++j) {
+            const bool lt = moved || k < key[j];
+            moved = lt;
+            const unsigned long long kk = lt ? key[j] : k;
+            const uint32_t ii = lt ? core[j] : id;
+            key[j] = lt ? k : key[j];
+            core[j] = lt ? id : core[j];
+            k = kk;
+            id = ii;
+        }
+    }
+    uint32_t w[kShort / 4];
+#pragma unroll
+    for (int j = 0; j < kShort / 4; ++j)
+        w[j] = core[4 * j] | (core[4 * j + 1] << 8) | (core[4 * j + 2] << 16) | (core[4 * j + 3] << 24);
+    *reinterpret_cast<uint4*>(out + (size_t)pair * kShort) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 // kThreads = 1024: 16 waves share an instance's bidding (shortest time for one placement);
 // kThreads = 256: more instances resident per CU (highest throughput for large batches).
 // SMALLINT: the instantiation for tables of small integers (bids from the 16-bit copy).  Which kind a table
@@ -160,7 +207,7 @@ template <int kThreads, bool SMALLINT>
 __global__ __launch_bounds__(kThreads, kThreads == 256 ? (SMALLINT ? QP_GT_WAVES_INT : QP_GT_WAVES) : 4) void k_gtrhqa_place(GpArgs p) {
     constexpr int kWaves = kThreads / kWave;
     extern __shared__ __align__(16) uint8_t smem[];
-    __shared__ int s_nops, s_nav, s_nleft, s_nfree, s_nneed, s_flag, s_wave_cnt[kWaves], s_base;
+    __shared__ int s_nops, s_nav, s_nleft, s_nfree, s_nneed, s_nscan, s_flag, s_wave_cnt[kWaves], s_base;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     const int C = p.C, Q = p.Q, ldq = p.ldq;
     uint8_t* rows = smem + p.off_rows;                                 // [2][ldq]
@@ -174,6 +221,7 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? (SMALLINT ? QP_GT_WAVES
     OpFlags* flags = reinterpret_cast<OpFlags*>(smem + p.off_flags);   // [max_ops]
     uint8_t* cfree = smem + p.off_cores;                               // [256] by core: 1 = a column of the slice and not taken yet
     uint16_t* need_list = reinterpret_cast<uint16_t*>(smem + p.off_need);  // [max_ops] ops that must bid again
+    uint16_t* scan_list = reinterpret_cast<uint16_t*>(smem + p.off_scan);  // [max_ops] those of them that must scan the table
 
     // all distances finite: then every entry is, and the "nothing finite left" test never fires
     const bool dfinite = p.all_finite[0] != 0;
@@ -181,7 +229,7 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? (SMALLINT ? QP_GT_WAVES
 
 #ifdef QP_GTRHQA_TIMING
     long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
-    long long n_rounds = 0, n_need = 0, n_left = 0;
+    long long n_rounds = 0, n_need = 0, n_left = 0, n_scan = 0;
 #endif
     for (int64_t b = blockIdx.x; b < p.B; b += gridDim.x) {
         uint8_t* outb = p.out + (size_t)b * (p.T + 1) * ldq;
@@ -259,6 +307,7 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? (SMALLINT ? QP_GT_WAVES
                 // A 16-lane row of a wave serves one bidding op; lane l of the row looks at cores 32 i + 2 l and
                 // 32 i + 2 l + 1, i = 0 .. 7: 16 bytes of a table row per load, 256 contiguous bytes per row of lanes.
                 const int l16 = lane & 15, rowi = lane >> 4;
+                const int nshort = min(C, kShort);  // entries of a short list that name a core
                 if (tid == 0) {
                     s_nleft = nops;
                     s_nfree = nav;
@@ -294,7 +343,40 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? (SMALLINT ? QP_GT_WAVES
                     n_rounds += 1;
                     n_need += nneed;
 #endif
-                    // each of them looks for its cheapest free core (first minimum); four ops per wave step.
+                    // First the short way: lane l of an op's row looks at entry l of the op's list of cheapest cores;
+                    // the first of them that is free is the op's bid.  Ops whose whole list is taken go on scan_list.
+                    const uint16_t* todo = need_list;
+                    int ntodo = nneed;
+                    if (dfinite) {
+                        if (tid == 0) s_nscan = 0;
+                        __syncthreads();
+                        for (int nb = wave * 4; nb < nneed; nb += kWaves * 4) {
+                            const int e = nb + rowi;
+                            const bool act = e < nneed;
+                            const int k = need_list[act ? e : nb];
+                            const uint32_t a1 = a12[k] & 0xFF, a2 = a12[k] >> 8;
+                            const uint32_t cand = p.shortlist[((size_t)a1 * C + a2) * kShort + l16];
+                            const bool ok = l16 < nshort && cfree[cand] != 0;  // (entries past the list's end read 0xFF: inside cfree)
+                            const uint32_t pos = rowmin_u32(ok ? (uint32_t)l16 : 0xFFu);
+                            if (pos != 0xFFu) {
+                                if ((uint32_t)l16 == pos && act) {
+                                    bid[k] = entry(p.D, a1, a2, cand);
+                                    target[k] = (int)cand;
+                                    flags[k] = OpFlags{1, 0, 1, 0};
+                                }
+                            } else if (l16 == 0 && act) {
+                                scan_list[atomicAdd(&s_nscan, 1)] = (uint16_t)k;
+                            }
+                        }
+                        __syncthreads();
+                        todo = scan_list;
+                        ntodo = s_nscan;
+                    }
+#ifdef QP_GTRHQA_TIMING
+                    n_scan += ntodo;
+#endif
+                    TIC(6);
+                    // the others look for their cheapest free core (first minimum) in the table; four ops per wave step.
                     // taken: bit 2 i + s set = this lane's core 32 i + 2 l16 + s is not a free column
                     uint32_t taken = 0;
 #pragma unroll
@@ -305,10 +387,10 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? (SMALLINT ? QP_GT_WAVES
                     bool isfree[16];  // the same per position, held as lane masks for the compares below
 #pragma unroll
                     for (int j = 0; j < 16; ++j) isfree[j] = ((taken >> j) & 1u) == 0;
-                    for (int nb = wave * 4; nb < nneed; nb += kWaves * 4) {
+                    for (int nb = wave * 4; nb < ntodo; nb += kWaves * 4) {
                         const int e = nb + rowi;
-                        const bool act = e < nneed;
-                        const int k = need_list[act ? e : nb];  // a row without an op of its own repeats the first
+                        const bool act = e < ntodo;
+                        const int k = todo[act ? e : nb];  // a row without an op of its own repeats the first
                         const uint32_t a1 = a12[k] & 0xFF, a2 = a12[k] >> 8;
                         // key = bits of the entry (non-negative doubles order like their bits); a lane looks at its
                         // cores in ascending order, so "<" keeps its first minimum; among the lanes of the row the
@@ -502,8 +584,8 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? (SMALLINT ? QP_GT_WAVES
         }
 #ifdef QP_GTRHQA_TIMING
         if (tid == 0 && b == 0)
-            printf("gtrhqa phases (cycles, instance 0, %d threads): setup %lld  needlist %lld  bid %lld  resolve %lld  leftover %lld  store %lld | rounds %lld  bids %lld  open after the rounds %lld\n",
-                   kThreads, tacc[0], tacc[1], tacc[2], tacc[3], tacc[4], tacc[5], n_rounds, n_need, n_left);
+            printf("gtrhqa phases (cycles, instance 0, %d threads): setup %lld  needlist %lld  short lists %lld  scans %lld  resolve %lld  leftover %lld  store %lld | rounds %lld  bids %lld  of them scans %lld  open after the rounds %lld\n",
+                   kThreads, tacc[0], tacc[1], tacc[6], tacc[2], tacc[3], tacc[4], tacc[5], n_rounds, n_need, n_scan, n_left);
 #endif
     }
 }
@@ -511,8 +593,8 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? (SMALLINT ? QP_GT_WAVES
 }  // namespace
 
 extern "C" size_t qp_gtrhqa_workspace(int32_t C) {
-    // fp64 copy at a row pitch of 256 entries, two flags, 16-bit copy at the same pitch
-    return C > 0 ? (size_t)C * kPitch * (sizeof(double) + sizeof(uint16_t)) + 16 : 16;
+    // fp64 copy at a row pitch of 256 entries, two flags, 16-bit copy at the same pitch, the short lists
+    return C > 0 ? (size_t)C * kPitch * (sizeof(double) + sizeof(uint16_t)) + 16 + (size_t)C * C * kShort : 16;
 }
 
 extern "C" int qp_gtrhqa_place(const QpCircuit* circ, const QpDTable* dt, const uint8_t* initial, int64_t B, int32_t ldq,
@@ -526,13 +608,16 @@ extern "C" int qp_gtrhqa_place(const QpCircuit* circ, const QpDTable* dt, const 
     if (cap < 2) return qp::fail(QP_EINVAL, "qp_gtrhqa_place: capacity must be at least 2");
     if (circ->T > 0 && (!circ->slice_edge_ptr || (circ->nE > 0 && !circ->edges)))
         return qp::fail(QP_EINVAL, "qp_gtrhqa_place: circuit edge tables missing");
-    if (!workspace || workspace_bytes < qp_gtrhqa_workspace(dt->C) || (reinterpret_cast<uintptr_t>(workspace) & 7))
-        return qp::fail(QP_ENOSPC, "qp_gtrhqa_place: workspace needs %zu bytes, 8-byte aligned", qp_gtrhqa_workspace(dt->C));
+    if (!workspace || workspace_bytes < qp_gtrhqa_workspace(dt->C) || (reinterpret_cast<uintptr_t>(workspace) & 15))
+        return qp::fail(QP_ENOSPC, "qp_gtrhqa_place: workspace needs %zu bytes, 16-byte aligned", qp_gtrhqa_workspace(dt->C));
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     double* Dz = static_cast<double*>(workspace);
     int32_t* all_finite = reinterpret_cast<int32_t*>(Dz + (size_t)dt->C * kPitch);
     uint16_t* Dz16 = reinterpret_cast<uint16_t*>(all_finite + 4);
+    uint8_t* shortlist = reinterpret_cast<uint8_t*>(Dz16 + (size_t)dt->C * kPitch);  // 16-byte aligned: everything before it is
     k_gtrhqa_prepare<<<1, 1024, 0, stream>>>(static_cast<const double*>(dt->table), dt->C, Dz, Dz16, all_finite);
+    HIP_TRY(hipGetLastError());
+    k_gtrhqa_shortlist<<<(unsigned)((dt->C * dt->C + 255) / 256), 256, 0, stream>>>(Dz, dt->C, shortlist);
     HIP_TRY(hipGetLastError());
 
     // the most counted gates any slice has sizes the per-op arrays: the caller's figure if it gave one
@@ -544,6 +629,7 @@ extern "C" int qp_gtrhqa_place(const QpCircuit* circ, const QpDTable* dt, const 
     p.D = Dz;
     p.D16 = Dz16;
     p.all_finite = all_finite;
+    p.shortlist = shortlist;
     p.initial = initial;
     p.out = out;
     p.B = B;
@@ -570,6 +656,7 @@ extern "C" int qp_gtrhqa_place(const QpCircuit* circ, const QpDTable* dt, const 
     p.off_flags = take((size_t)4 * max_ops);
     p.off_cores = take((size_t)kPitch);
     p.off_need = take((size_t)2 * max_ops);
+    p.off_scan = take((size_t)2 * max_ops);
     if (off > 160u * 1024u) return qp::fail(QP_EINVAL, "qp_gtrhqa_place: circuit too wide for the on-chip state (%u bytes)", off);
     const int cus = qp::device_cus();
     int per_cu = 1;

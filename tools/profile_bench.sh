@@ -3,7 +3,7 @@
 # 1. rocprofv3 --kernel-trace --stats of the default bench.py (without the CPU baseline leg);
 # 2. per variant (uniform, integer, integer with look-ups forced), two --pmc passes (FETCH_SIZE, WRITE_SIZE: each in its own run) for the HBM traffic of
 #    the cost-only bench.  Summaries go to gpurun_out/<tag>_*.csv and gpurun_out/<tag>_traffic.json (copy the
-#    latter to profiles/r02_traffic.json: bench.py reads it); raw traces are deleted.
+#    latter to profiles/r03_traffic.json: bench.py reads it); raw traces are deleted.
 set -e
 tag=$1
 export TMPDIR=/tmp
