@@ -156,7 +156,10 @@ __global__ void k_gtrhqa_prepare(const double* D, int C, double* Dz, uint16_t* D
 // all; only an op whose kShort best cores are all gone has to scan the table.  One thread per pair, an insertion into
 // a sorted array per core; built once per call (the table is fixed for all slices of all instances).  0xFF = no core
 // (fewer than kShort cores).
-constexpr int kShort = 16;
+#ifndef QP_GT_SHORT
+#define QP_GT_SHORT 16
+#endif
+constexpr int kShort = QP_GT_SHORT;  // 16 or 32
 
 __global__ __launch_bounds__(256) void k_gtrhqa_shortlist(const double* Dz, int C, uint8_t* out) {
     const int pair = blockIdx.x * blockDim.x + threadIdx.x;
@@ -192,7 +195,9 @@ __global__ __launch_bounds__(256) void k_gtrhqa_shortlist(const double* Dz, int 
 #pragma unroll
     for (int j = 0; j < kShort / 4; ++j)
         w[j] = core[4 * j] | (core[4 * j + 1] << 8) | (core[4 * j + 2] << 16) | (core[4 * j + 3] << 24);
-    *reinterpret_cast<uint4*>(out + (size_t)pair * kShort) = make_uint4(w[0], w[1], w[2], w[3]);
+#pragma unroll
+    for (int j = 0; j < kShort / 16; ++j)
+        *reinterpret_cast<uint4*>(out + (size_t)pair * kShort + 16 * j) = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
 }
 
 // kThreads = 1024: 16 waves share an instance's bidding (shortest time for one placement);
@@ -317,6 +322,7 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? (SMALLINT ? QP_GT_WAVES
                 __syncthreads();
                 const int max_rounds = min(nav, nops) + 2;
                 int rounds = 0;
+                bool use_short = dfinite;  // bids from the short lists (tables with an infinite entry always scan)
                 while (s_nleft > 0 && s_nfree > 0 && rounds < max_rounds) {
                     ++rounds;
                     if (!dfinite) {  // :135-137: stop when no open op has a finite entry on a free core
@@ -347,7 +353,7 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? (SMALLINT ? QP_GT_WAVES
                     // the first of them that is free is the op's bid.  Ops whose whole list is taken go on scan_list.
                     const uint16_t* todo = need_list;
                     int ntodo = nneed;
-                    if (dfinite) {
+                    if (use_short) {
                         if (tid == 0) s_nscan = 0;
                         __syncthreads();
                         for (int nb = wave * 4; nb < nneed; nb += kWaves * 4) {
@@ -355,11 +361,19 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? (SMALLINT ? QP_GT_WAVES
                             const bool act = e < nneed;
                             const int k = need_list[act ? e : nb];
                             const uint32_t a1 = a12[k] & 0xFF, a2 = a12[k] >> 8;
-                            const uint32_t cand = p.shortlist[((size_t)a1 * C + a2) * kShort + l16];
-                            const bool ok = l16 < nshort && cfree[cand] != 0;  // (entries past the list's end read 0xFF: inside cfree)
-                            const uint32_t pos = rowmin_u32(ok ? (uint32_t)l16 : 0xFFu);
+                            // lane l looks at entries l, l + 16, ... of the list (entries past its end read 0xFF: inside cfree)
+                            uint32_t cand = 0, mine = 0xFFu;
+#pragma unroll
+                            for (int h = kShort / 16 - 1; h >= 0; --h) {
+                                const uint32_t c = p.shortlist[((size_t)a1 * C + a2) * kShort + 16 * h + l16];
+                                if (16 * h + l16 < nshort && cfree[c] != 0) {
+                                    cand = c;
+                                    mine = (uint32_t)(16 * h + l16);
+                                }
+                            }
+                            const uint32_t pos = rowmin_u32(mine);
                             if (pos != 0xFFu) {
-                                if ((uint32_t)l16 == pos && act) {
+                                if (mine == pos && act) {
                                     bid[k] = entry(p.D, a1, a2, cand);
                                     target[k] = (int)cand;
                                     flags[k] = OpFlags{1, 0, 1, 0};
@@ -371,6 +385,9 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? (SMALLINT ? QP_GT_WAVES
                         __syncthreads();
                         todo = scan_list;
                         ntodo = s_nscan;
+                        // a slice whose cheapest cores are contested (equal entries everywhere, as integer weights
+                        // give them) exhausts the lists: once most of a round's look-ups fail, the rest of the slice scans
+                        if (2 * ntodo > nneed) use_short = false;
                     }
 #ifdef QP_GTRHQA_TIMING
                     n_scan += ntodo;
