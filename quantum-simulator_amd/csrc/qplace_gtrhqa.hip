@@ -156,10 +156,7 @@ __global__ void k_gtrhqa_prepare(const double* D, int C, double* Dz, uint16_t* D
 // all; only an op whose kShort best cores are all gone has to scan the table.  One thread per pair, an insertion into
 // a sorted array per core; built once per call (the table is fixed for all slices of all instances).  0xFF = no core
 // (fewer than kShort cores).
-#ifndef QP_GT_SHORT
-#define QP_GT_SHORT 16
-#endif
-constexpr int kShort = QP_GT_SHORT;  // 16 or 32
+constexpr int kShort = 16;  // (32 measured slower: the look-up costs more than the scans it saves)
 
 __global__ __launch_bounds__(256) void k_gtrhqa_shortlist(const double* Dz, int C, uint8_t* out) {
     const int pair = blockIdx.x * blockDim.x + threadIdx.x;
@@ -356,30 +353,41 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? (SMALLINT ? QP_GT_WAVES
                     if (use_short) {
                         if (tid == 0) s_nscan = 0;
                         __syncthreads();
-                        for (int nb = wave * 4; nb < nneed; nb += kWaves * 4) {
-                            const int e = nb + rowi;
+                        // a thread per op: its list is one 16-byte load, the sixteen "is this core free" bytes are read
+                        // together, the first free entry wins (walked from the back so that the earliest one is kept)
+                        static_assert(kShort == 16, "a short list is one 16-byte load");
+                        for (int e0 = 0; e0 < nneed; e0 += kThreads) {
+                            const int e = e0 + tid;
                             const bool act = e < nneed;
-                            const int k = need_list[act ? e : nb];
+                            const int k = need_list[act ? e : 0];
                             const uint32_t a1 = a12[k] & 0xFF, a2 = a12[k] >> 8;
-                            // lane l looks at entries l, l + 16, ... of the list (entries past its end read 0xFF: inside cfree)
-                            uint32_t cand = 0, mine = 0xFFu;
+                            const uint4 lst = *reinterpret_cast<const uint4*>(p.shortlist + ((size_t)a1 * C + a2) * kShort);
+                            const uint32_t w[4] = {lst.x, lst.y, lst.z, lst.w};
+                            uint32_t fr[kShort];
 #pragma unroll
-                            for (int h = kShort / 16 - 1; h >= 0; --h) {
-                                const uint32_t c = p.shortlist[((size_t)a1 * C + a2) * kShort + 16 * h + l16];
-                                if (16 * h + l16 < nshort && cfree[c] != 0) {
-                                    cand = c;
-                                    mine = (uint32_t)(16 * h + l16);
+                            for (int j = 0; j < kShort; ++j) fr[j] = cfree[(w[j >> 2] >> (8 * (j & 3))) & 0xFFu];  // (0xFF past the list's end: inside cfree)
+                            uint32_t core = 0;
+                            bool found = false;
+#pragma unroll
+                            for (int j = kShort - 1; j >= 0; --j) {
+                                if (j < nshort && fr[j] != 0) {
+                                    core = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+                                    found = true;
                                 }
                             }
-                            const uint32_t pos = rowmin_u32(mine);
-                            if (pos != 0xFFu) {
-                                if (mine == pos && act) {
-                                    bid[k] = entry(p.D, a1, a2, cand);
-                                    target[k] = (int)cand;
-                                    flags[k] = OpFlags{1, 0, 1, 0};
-                                }
-                            } else if (l16 == 0 && act) {
-                                scan_list[atomicAdd(&s_nscan, 1)] = (uint16_t)k;
+                            if (act && found) {
+                                bid[k] = entry(p.D, a1, a2, core);
+                                target[k] = (int)core;
+                                flags[k] = OpFlags{1, 0, 1, 0};
+                            }
+                            const bool scan = act && !found;
+                            const unsigned long long m = __ballot(scan);
+                            if (m) {  // one list-counter update per wave
+                                const int leader = __ffsll((long long)m) - 1;
+                                int base = 0;
+                                if (lane == leader) base = atomicAdd(&s_nscan, __popcll(m));
+                                base = __builtin_amdgcn_readlane(base, leader);
+                                if (scan) scan_list[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)k;
                             }
                         }
                         __syncthreads();
