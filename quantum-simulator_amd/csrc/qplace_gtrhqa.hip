@@ -156,7 +156,10 @@ __global__ void k_gtrhqa_prepare(const double* D, int C, double* Dz, uint16_t* D
 // all; only an op whose kShort best cores are all gone has to scan the table.  One thread per pair, an insertion into
 // a sorted array per core; built once per call (the table is fixed for all slices of all instances).  0xFF = no core
 // (fewer than kShort cores).
-constexpr int kShort = 16;  // (32 measured slower: the look-up costs more than the scans it saves)
+#ifndef QP_GT_SHORT
+#define QP_GT_SHORT 16
+#endif
+constexpr int kShort = QP_GT_SHORT;  // a multiple of 16
 
 __global__ __launch_bounds__(256) void k_gtrhqa_shortlist(const double* Dz, int C, uint8_t* out) {
     const int pair = blockIdx.x * blockDim.x + threadIdx.x;
@@ -355,14 +358,21 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? (SMALLINT ? QP_GT_WAVES
                         __syncthreads();
                         // a thread per op: its list is one 16-byte load, the sixteen "is this core free" bytes are read
                         // together, the first free entry wins (walked from the back so that the earliest one is kept)
-                        static_assert(kShort == 16, "a short list is one 16-byte load");
+                        static_assert(kShort % 16 == 0, "a short list is read in 16-byte loads");
                         for (int e0 = 0; e0 < nneed; e0 += kThreads) {
                             const int e = e0 + tid;
                             const bool act = e < nneed;
                             const int k = need_list[act ? e : 0];
                             const uint32_t a1 = a12[k] & 0xFF, a2 = a12[k] >> 8;
-                            const uint4 lst = *reinterpret_cast<const uint4*>(p.shortlist + ((size_t)a1 * C + a2) * kShort);
-                            const uint32_t w[4] = {lst.x, lst.y, lst.z, lst.w};
+                            uint32_t w[kShort / 4];
+#pragma unroll
+                            for (int h = 0; h < kShort / 16; ++h) {
+                                const uint4 lst = *reinterpret_cast<const uint4*>(p.shortlist + ((size_t)a1 * C + a2) * kShort + 16 * h);
+                                w[4 * h] = lst.x;
+                                w[4 * h + 1] = lst.y;
+                                w[4 * h + 2] = lst.z;
+                                w[4 * h + 3] = lst.w;
+                            }
                             uint32_t fr[kShort];
 #pragma unroll
                             for (int j = 0; j < kShort; ++j) fr[j] = cfree[(w[j >> 2] >> (8 * (j & 3))) & 0xFFu];  // (0xFF past the list's end: inside cfree)
