@@ -603,6 +603,8 @@ __global__ void k_qubo_finish(int32_t* e, int32_t R, int32_t constant) {
 // core loads and slack bits live in registers while their lane owns the core.
 // ------------------------------------------------------------------------------------------------
 
+constexpr int kHopPlanes = 5;  // hop counts up to 31
+
 struct SaArgs {
     QpQuboStruct m;
     int8_t* Xt;
@@ -696,6 +698,28 @@ __global__ __launch_bounds__(256) void k_qubo_anneal(SaArgs p) {
     const int S = C <= 64 ? max(1, 64 / C) : 1;  // slices updated side by side
     const int ls = lane / C, lj = lane - ls * C;
     const bool lane_used = ls < S;
+    // bit planes of the lane's row and column of the hop table: bit l of prow[k] = bit k of hop[lj][l], of pcol[k] = bit k
+    // of hop[l][lj]; hop counts between at most 32 connected cores are at most 31
+    uint32_t prow[kHopPlanes], pcol[kHopPlanes];
+    int nplanes = 1;
+    {
+        uint32_t top = 0;
+#pragma unroll
+        for (int kpl = 0; kpl < kHopPlanes; ++kpl) prow[kpl] = pcol[kpl] = 0;
+        for (int l = 0; l < C; ++l) {
+            const uint32_t hr = lane_used ? hop[lj * C + l] : 0u, hc = lane_used ? hop[l * C + lj] : 0u;
+            top |= hr | hc;
+#pragma unroll
+            for (int kpl = 0; kpl < kHopPlanes; ++kpl) {
+                prow[kpl] |= ((hr >> kpl) & 1u) << l;
+                pcol[kpl] |= ((hc >> kpl) & 1u) << l;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) top |= __shfl_xor(top, o, 64);
+        while (nplanes < kHopPlanes && (top >> nplanes)) ++nplanes;
+        nplanes = __builtin_amdgcn_readfirstlane(nplanes);
+    }
     int dEsum = 0;
     for (int sweep = 0; sweep < p.sweeps; ++sweep) {
         const float beta = -1.44269504088896f * p.beta_hot *
@@ -715,8 +739,6 @@ __global__ __launch_bounds__(256) void k_qubo_anneal(SaArgs p) {
                 uint32_t* mk = mask + (size_t)(on ? t : 0) * nmax;
                 const size_t tb = (size_t)(on ? t : 0) * nmax;
                 const uint64_t* infp = m.info + tb;
-                const uint8_t* hrow = hop + lj * C;  // hop[lj][.]
-                const uint8_t* hcol = hop + lj;      // hop[.][lj] at stride C
                 const int blocks = (nb + C - 1) / C;
                 for (int mb = 0; mb < blocks; ++mb) {
                     for (int step = 0; step < C; ++step) {
@@ -731,26 +753,26 @@ __global__ __launch_bounds__(256) void k_qubo_anneal(SaArgs p) {
                             const uint64_t inf = infp[i];
                             const uint32_t ilo = (uint32_t)inf, ihi = (uint32_t)(inf >> 32);
                             const int dg = (int)(ilo & 0xFFu);
+                            // the three words this proposal looks at besides its own: the first partner's, the same
+                            // qubit's in the two neighbouring slices ("none" is a word that stays zero): read together
+                            const uint32_t pw = mask[ilo >> 16];
+                            const uint32_t o1 = mask[ihi & 0xFFFFu], o2 = mask[ihi >> 16];
                             int lap;
                             if (dg <= 1) {
-                                lap = dg - 2 * (int)((uint32_t)dg & (mask[ilo >> 16] >> lj));
+                                lap = dg - 2 * (int)((uint32_t)dg & (pw >> lj));
                             } else {
                                 lap = dg;
                                 for (int e = m.nbr_ptr[tb + i]; e < m.nbr_ptr[tb + i + 1]; ++e)
                                     lap -= 2 * (int)((mk[m.nbr[e]] >> lj) & 1u);
                             }
-                            // hops to wherever the same qubit sits in the neighbouring slices (one bit per
-                            // word once the state is one-hot)
-                            uint32_t o1 = mask[ihi & 0xFFFFu], o2 = mask[ihi >> 16];
+                            // hops to wherever the same qubit sits in the neighbouring slices: sum over the set bits l of
+                            // hop[lj][l] (next slice) and hop[l][lj] (previous), from the bit planes of the lane's row and
+                            // column of the hop table: bit k of the sum's terms is a population count
                             int mv = 0;
-                            while (o1) {
-                                mv += hrow[__builtin_ctz(o1)];
-                                o1 &= o1 - 1;
-                            }
-                            while (o2) {
-                                mv += hcol[__mul24(__builtin_ctz(o2), C)];
-                                o2 &= o2 - 1;
-                            }
+#pragma unroll
+                            for (int kpl = 0; kpl < kHopPlanes; ++kpl)
+                                if (kpl < nplanes)
+                                    mv += (__popc(o1 & prow[kpl]) + __popc(o2 & pcol[kpl])) << kpl;
                             const int bit = (w >> lj) & 1u;
                             const int d = 1 - 2 * bit;
                             const int Ai = __popc(w);
