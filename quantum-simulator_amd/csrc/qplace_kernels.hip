@@ -11,6 +11,10 @@
 
 #include "qplace_internal.h"
 
+#ifndef QP_GROUPS4_AHEAD
+#define QP_GROUPS4_AHEAD 2
+#endif
+
 namespace {
 
 constexpr int kWave = 64;
@@ -615,6 +619,255 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void k_cost_v3_gro
                     gacc = GridAcc();
                     s = 0;
                     ++cp;
+                }
+            }
+        }
+    }
+}
+
+// The table forms of k_cost_v3_groups, four partitions per wave step.  The gates of a group of slices are the same for
+// every partition, so a wave takes the group's rows of four consecutive partitions in one step (a lane: its
+// 16-byte piece of each) and parks them interleaved: strip word (row, q) = the cores of qubit q in the four
+// partitions.  One ds_read_b32 then fetches a gate endpoint for all four (two gathers per step and partition
+// instead of eight), and a pair of words, (row before, row) of a qubit or (first, second endpoint) of a gate, is
+// four look-ups, one partition per byte lane, each into that partition's own sum.  A qubit that moved in none of
+// the four partitions, and a gate whose qubits share a core in all four, look nothing up.
+// Strip of a wave: [row before][G rows] of words; a lane's sixteen words go out as four 16-byte writes whose
+// quarters are permuted between lane pairs (word index i sits at i ^ (((i >> 5) & 3) << 2), indices counted from
+// the first of the G rows, negative in the row before), so that the eight lanes of an LDS pass hit all 32 banks.
+// Items: as in k_cost_v3_groups with a quad of partitions in the place of a partition; a last quad that is not
+// full repeats the batch's last partition and drops the copies.
+constexpr int kGroups4Threads = 512;
+constexpr int kGroups4Ahead = QP_GROUPS4_AHEAD;
+
+template <int KIND, int TABMODE, int AHEAD>
+__global__ __launch_bounds__(kGroups4Threads, 4) void k_cost_v3_groups4(V3Args p) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    using E = typename Tab<KIND>::elem;
+    using Acc = typename Tab<KIND>::acc;
+    static_assert(kRowEdgeChunks == 4, "four gate chunks per step are prefetched");
+    static_assert(TABMODE == kTabLds256 || TABMODE == kTabLdsRep4 || TABMODE == kTabLdsRep6, "LDS tables indexed by packed core pairs");
+    constexpr int kWaves = kGroups4Threads / kWave;
+    constexpr uint32_t kIdBits = TABMODE == kTabLdsRep4 ? 0x0F0F0F0Fu : TABMODE == kTabLdsRep6 ? 0x3F3F3F3Fu : 0xFFFFFFFFu;
+    constexpr int kIdShift = TABMODE == kTabLdsRep6 ? 2 : 0;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    uint32_t tab_off;
+    if constexpr (TABMODE == kTabLds256) tab_off = stage_table_pitch256<E>(smem, p.table, p.C);
+    else if constexpr (TABMODE == kTabLdsRep4) tab_off = stage_table_replicated<E, 4>(smem, p.table, p.C, p.rep_shift);
+    else tab_off = stage_table_replicated<E, 6>(smem, p.table, p.C, p.rep_shift);
+    using RepE = typename std::conditional<sizeof(E) == 2, uint32_t, E>::type;  // a stored copy of an entry
+    typedef __attribute__((address_space(3))) const RepE lds_rep;
+    const int ldq = p.ldq, G = p.G, lpr = p.lpr;
+    const uint32_t tbase = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_u8*)smem);
+    const uint32_t rep_pitch = ((uint32_t)sizeof(RepE) << p.rep_shift) >> kIdShift;  // bytes per unit of a half
+    const uint32_t rep_base = tbase + (uint32_t)(lane & ((1 << p.rep_shift) - 1)) * (uint32_t)sizeof(RepE);
+    auto rep_at_halves = [&](uint32_t x, RepE& e0, RepE& e1) {  // the entries whose indices are the halves of x
+        uint32_t a0, a1;
+        asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[0,0,0,0]" : "=v"(a0) : "v"(x), "s"(rep_pitch), "v"(rep_base));
+        asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(a1) : "v"(x), "s"(rep_pitch), "v"(rep_base));
+        e0 = *(lds_rep*)(uintptr_t)a0;
+        e1 = *(lds_rep*)(uintptr_t)a1;
+    };
+    const uint32_t strip_words = (uint32_t)(G + 1) * (uint32_t)ldq;
+    uint32_t* rows = reinterpret_cast<uint32_t*>(smem + tab_off) + (size_t)wave * strip_words + ldq;  // word (row, q) of the step
+    const uint32_t rbase = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_u8*)smem + tab_off + ((uint32_t)wave * strip_words + (uint32_t)ldq) * 4u);
+    const bool lane_on = lane < G * lpr;
+    const int lrow = lane_on ? lane / lpr : 0;
+    const int lq0 = lane_on ? (lane - lrow * lpr) * 16 : 0;
+    const int lane_off = lane_on ? lane * 16 : 0;  // = lrow * ldq + lq0: word index of the lane's piece
+    const bool last_row = lane_on && lrow == G - 1;
+    const int nvalid = lane_on ? min(16, max(0, p.Q - lq0)) : 0;  // qubits of the piece that exist
+    // Core ids as the strip holds them: bytes past the row's last qubit cleared (they then never differ between rows
+    // and look up the zero diagonal), ids cut to the table's range, and for tables of up to 64 cores ids times four:
+    // the halves (from / 4) << 8 | to of a packed pair are then (from << 6 | to) << 2, a multiple of the entry index, and
+    // one v_mad_u32_u16 turns a half into an address.
+    uint32_t keep[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const int nb = min(4, max(0, nvalid - 4 * w));
+        keep[w] = ((nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u)) & kIdBits) << kIdShift;
+    }
+    auto ids = [&](const uint4& v) { return make_uint4((v.x << kIdShift) & keep[0], (v.y << kIdShift) & keep[1], (v.z << kIdShift) & keep[2], (v.w << kIdShift) & keep[3]); };
+    auto quarter = [](int piece, int w) { return piece + 4 * (w ^ ((piece >> 5) & 3)); };  // where words 4w .. 4w + 3 of a piece sit
+
+    const uint32_t* gsched_lane = p.gsched + lane;
+    const size_t pstride = (size_t)p.Tp * ldq;
+    for (int64_t it = (int64_t)blockIdx.x * kWaves + wave; it < p.nitems; it += (int64_t)gridDim.x * kWaves) {
+        // an item: a run of whole groups of slices (rows r0 .. r1 - 1) of nq consecutive quads of partitions; nq > 1
+        // only when the run is the whole circuit, and the wave then walks the quads as one stream of steps
+        const int chunk = (int)(it / p.nbgroups);
+        const int64_t b0 = (it - (int64_t)chunk * p.nbgroups) * p.parts_per_item * 4;
+        const int nq = (int)min((int64_t)p.parts_per_item, (p.B - b0 + 3) / 4);
+        const int r0 = chunk * p.rows_per_item;  // a multiple of G
+        const int r1 = min(p.T, r0 + p.rows_per_item);
+        const int nsteps = (r1 - r0 + G - 1) / G;
+        const int j0 = r0 / G;
+        const int N = nq * nsteps;
+        Acc acc[4] = {0, 0, 0, 0};
+
+        // one look-up per partition: the byte lanes of (from, to) are the partitions
+        auto look4 = [&](uint32_t from, uint32_t to) {
+            if constexpr (TABMODE == kTabLds256) {
+                E e0, e1, e2, e3;
+                entries_at_halves<E>(__builtin_amdgcn_perm(from, to, 0x05010400u), tbase, e0, e1);
+                entries_at_halves<E>(__builtin_amdgcn_perm(from, to, 0x07030602u), tbase, e2, e3);
+                acc[0] += (Acc)e0;
+                acc[1] += (Acc)e1;
+                acc[2] += (Acc)e2;
+                acc[3] += (Acc)e3;
+            } else {
+                RepE e0, e1, e2, e3;
+                if constexpr (TABMODE == kTabLdsRep4) {
+                    const uint32_t k = (from << 4) | to;  // from << 4 | to, a byte each
+                    rep_at_halves(__builtin_amdgcn_perm(0u, k, 0x0c010c00u), e0, e1);
+                    rep_at_halves(__builtin_amdgcn_perm(0u, k, 0x0c030c02u), e2, e3);
+                } else {  // ids times four: with the source ids shifted back a half is four times from << 6 | to
+                    const uint32_t f = from >> 2;
+                    rep_at_halves(__builtin_amdgcn_perm(f, to, 0x05010400u), e0, e1);
+                    rep_at_halves(__builtin_amdgcn_perm(f, to, 0x07030602u), e2, e3);
+                }
+                acc[0] += (Acc)e0;
+                acc[1] += (Acc)e1;
+                acc[2] += (Acc)e2;
+                acc[3] += (Acc)e3;
+            }
+        };
+        // word w of the four partitions' pieces -> the words of qubits 4w .. 4w + 3 (4 x 4 byte transposes)
+        auto interleave = [&](const uint4 (&x)[4], uint32_t (&o)[16]) {
+            const uint32_t xw[4][4] = {{x[0].x, x[0].y, x[0].z, x[0].w}, {x[1].x, x[1].y, x[1].z, x[1].w},
+                                       {x[2].x, x[2].y, x[2].z, x[2].w}, {x[3].x, x[3].y, x[3].z, x[3].w}};
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const uint32_t t01a = __builtin_amdgcn_perm(xw[1][w], xw[0][w], 0x05010400u);  // a0 b0 a1 b1
+                const uint32_t t01b = __builtin_amdgcn_perm(xw[1][w], xw[0][w], 0x07030602u);  // a2 b2 a3 b3
+                const uint32_t t23a = __builtin_amdgcn_perm(xw[3][w], xw[2][w], 0x05010400u);  // c0 d0 c1 d1
+                const uint32_t t23b = __builtin_amdgcn_perm(xw[3][w], xw[2][w], 0x07030602u);
+                o[4 * w + 0] = __builtin_amdgcn_perm(t23a, t01a, 0x05040100u);  // a0 b0 c0 d0
+                o[4 * w + 1] = __builtin_amdgcn_perm(t23a, t01a, 0x07060302u);
+                o[4 * w + 2] = __builtin_amdgcn_perm(t23b, t01b, 0x05040100u);
+                o[4 * w + 3] = __builtin_amdgcn_perm(t23b, t01b, 0x07060302u);
+            }
+        };
+        auto park = [&](const uint32_t (&o)[16], int piece) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+                *reinterpret_cast<uint4*>(rows + quarter(piece, w)) = make_uint4(o[4 * w], o[4 * w + 1], o[4 * w + 2], o[4 * w + 3]);
+        };
+        // both endpoints of a packed gate word, for the four partitions
+        auto endpoints = [&](uint32_t g, uint32_t& u4, uint32_t& v4) {
+            const uint32_t x = g ^ ((g >> 3) & 0x000C000Cu);
+            uint32_t a0, a1;
+            asm("v_mad_u32_u16 %0, %1, 4, %2 op_sel:[0,0,0,0]" : "=v"(a0) : "v"(x), "s"(rbase));
+            asm("v_mad_u32_u16 %0, %1, 4, %2 op_sel:[1,0,0,0]" : "=v"(a1) : "v"(x), "s"(rbase));
+            u4 = *(lds_u32*)(uintptr_t)a0;
+            v4 = *(lds_u32*)(uintptr_t)a1;
+        };
+
+        // the next step of the stream (quad fq, step fs): the lane's piece of its rows in the four partitions (rows
+        // past the run's end repeat its last row, never counted) and the first gate chunks of its group; past the
+        // end of the stream the last step is requested again
+        int fq = 0, fs = 0;
+        auto fetch_next = [&](uint4 (&rslot)[4], uint32_t (&gslot)[kRowEdgeChunks]) {
+            const int rowl = min(r0 + fs * G + lrow, r1 - 1);
+            const uint32_t off = (uint32_t)rowl * (uint32_t)ldq + (uint32_t)lq0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int64_t b = min(b0 + 4 * (int64_t)fq + g, p.B - 1);  // wave-uniform
+                rslot[g] = load_row16(p.A + (size_t)b * pstride + off);  // (raw: ids() is applied when the step is worked on)
+            }
+            const uint32_t* gp = gsched_lane + p.gptr[j0 + fs];
+#pragma unroll
+            for (int c = 0; c < kRowEdgeChunks; ++c) gslot[c] = gp[c * kWave];
+            if (fs + 1 < nsteps) {
+                ++fs;
+            } else if (fq + 1 < nq) {
+                fs = 0;
+                ++fq;
+            }
+        };
+
+        if (r0 >= 1 && lane < lpr) {  // the row before the run (nq == 1 here)
+            uint4 x[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                x[g] = ids(*reinterpret_cast<const uint4*>(p.A + (size_t)min(b0 + g, p.B - 1) * pstride + (size_t)(r0 - 1) * ldq + lane * 16));
+            uint32_t o[16];
+            interleave(x, o);
+            park(o, lane * 16 - ldq);
+        }
+        uint4 ring[AHEAD][4];
+        uint32_t gring[AHEAD][kRowEdgeChunks];
+#pragma unroll
+        for (int k = 0; k < AHEAD; ++k) fetch_next(ring[k], gring[k]);
+
+        int cq = 0, s = 0;  // the step being worked on: quad cq of the item, step s
+        for (int n0 = 0; n0 < N; n0 += AHEAD) {
+#pragma unroll
+            for (int k = 0; k < AHEAD; ++k) {
+                if (n0 + k >= N) break;
+                uint32_t cur[16], gates[kRowEdgeChunks];
+                {
+                    const uint4 x[4] = {ids(ring[k][0]), ids(ring[k][1]), ids(ring[k][2]), ids(ring[k][3])};
+                    interleave(x, cur);
+                }
+#pragma unroll
+                for (int c = 0; c < kRowEdgeChunks; ++c) gates[c] = gring[k][c];
+                fetch_next(ring[k], gring[k]);
+
+                if (lane_on) park(cur, lane_off);
+                const int w0 = p.gptr[j0 + s];
+                const int nch = (p.gptr[j0 + s + 1] - w0) / kWave;
+                uint32_t U[kRowEdgeChunks], V[kRowEdgeChunks];
+#pragma unroll
+                for (int c = 0; c < kRowEdgeChunks; ++c) endpoints(c < nch ? gates[c] : 0u, U[c], V[c]);  // a chunk the group lacks: one word twice
+                // movement: rows 2 .. r1 - 1, row before -> this row, two qubits at a time (the look-ups of a pair
+                // are in flight together; a qubit that stayed looks up the zero diagonal)
+                const int row = r0 + s * G + lrow;
+                const bool mv = lane_on && row >= 2 && row < r1;
+                const int before = lane_off - ldq;  // the same piece one row earlier
+                uint32_t prv[16];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(rows + quarter(before, w));
+                    prv[4 * w] = v.x;
+                    prv[4 * w + 1] = v.y;
+                    prv[4 * w + 2] = v.z;
+                    prv[4 * w + 3] = v.w;
+                }
+                // the group's last row is "the row before" of the next step (after every lane has read its own)
+                if (last_row) park(cur, lq0 - ldq);
+#pragma unroll
+                for (int j = 0; j < 16; j += 2) {
+                    if (mv && ((prv[j] ^ cur[j]) | (prv[j + 1] ^ cur[j + 1])) != 0) {
+                        look4(prv[j], cur[j]);
+                        look4(prv[j + 1], cur[j + 1]);
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < kRowEdgeChunks; c += 2) {
+                    if (((U[c] ^ V[c]) | (U[c + 1] ^ V[c + 1])) != 0) {
+                        look4(U[c], V[c]);
+                        look4(U[c + 1], V[c + 1]);
+                    }
+                }
+                for (int c = kRowEdgeChunks; c < nch; ++c) {
+                    uint32_t u4, v4;
+                    endpoints(gsched_lane[w0 + c * kWave], u4, v4);
+                    if (u4 != v4) look4(u4, v4);
+                }
+                if (s + 1 < nsteps) {
+                    ++s;
+                } else {  // the quad's run is done: its four sums, and a fresh start for the next quad
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const double sum = wave_sum(acc[g]);
+                        const int64_t b = b0 + 4 * (int64_t)cq + g;
+                        if (lane == 0 && b < p.B) p.partial[(size_t)chunk * p.B + b] = sum;
+                        acc[g] = 0;
+                    }
+                    s = 0;
+                    ++cq;
                 }
             }
         }
@@ -2918,6 +3171,38 @@ int slice_cost_v3_impl(const char* fn, const QpCircuit* circ, const QpDTable* dt
             } else if (tab_padded + strips <= (size_t)kLdsBytes) {
                 mode = kTabLdsC;
                 tab_lds = tab_padded;
+            }
+            // LDS tables indexed by packed core pairs, 64 partitions or more: four partitions per wave step (a last
+            // quad that is not full repeats a partition, which is at most 5 % more work from 64 partitions on)
+            const size_t strips4 = (size_t)(kGroups4Threads / kWave) * (G + 1) * ldq * 4;
+            if (!one_row_groups && B >= 64 && (mode == kTabLdsRep4 || mode == kTabLdsRep6 || mode == kTabLds256) &&
+                tab_lds + strips4 <= (size_t)kLdsBytes) {
+                const int64_t nquads = (B + 3) / 4;
+                const int64_t want4 = steps_total * nquads / ((int64_t)cus * 16 * 4);
+                const int64_t spi4 = std::min<int64_t>(steps_total, std::min<int64_t>(256, std::max<int64_t>(8, want4)));
+                q.rows_per_item = (int)(spi4 * G);
+                const int32_t chunks4 = (T + q.rows_per_item - 1) / q.rows_per_item;
+                q.parts_per_item = 1;  // in quads
+                if (chunks4 == 1)
+                    q.parts_per_item = (int)std::max<int64_t>(1, std::min<int64_t>({256 / steps_total, 16, nquads / ((int64_t)cus * 16 * 2)}));
+                q.nbgroups = (nquads + q.parts_per_item - 1) / q.parts_per_item;
+                q.nitems = (int64_t)chunks4 * q.nbgroups;
+                if (int rc = need_workspace((size_t)chunks4 * B * sizeof(double))) return rc;
+                void (*kern4)(V3Args) = nullptr;
+#define QP_GROUPS4(MODE) (dt->kind == QP_DT_F64 ? k_cost_v3_groups4<QP_DT_F64, MODE, kGroups4Ahead> : k_cost_v3_groups4<QP_DT_U16, MODE, kGroups4Ahead>)
+                kern4 = mode == kTabLdsRep4 ? QP_GROUPS4(kTabLdsRep4) : mode == kTabLdsRep6 ? QP_GROUPS4(kTabLdsRep6) : QP_GROUPS4(kTabLds256);
+#undef QP_GROUPS4
+                const size_t lds4 = tab_lds + strips4;
+                const int waves4 = kGroups4Threads / kWave;
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
+                int per_cu4 = 1;
+                HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu4, reinterpret_cast<const void*>(kern4), kGroups4Threads, lds4));
+                const unsigned grid4 = (unsigned)std::min<int64_t>((int64_t)cus * std::max(per_cu4, 1), (q.nitems + waves4 - 1) / waves4);
+                kern4<<<grid4, kGroups4Threads, lds4, stream>>>(q);
+                HIP_TRY(hipGetLastError());
+                k_sum_chunks<<<(unsigned)((B + 255) / 256), 256, 0, stream>>>(q.partial, B, chunks4, out);
+                HIP_TRY(hipGetLastError());
+                return QP_OK;
             }
             // workgroups of 8 waves when three or more of them fit a CU (24 waves or more in flight where one
             // workgroup of 16 waves would be alone: the registers of this kernel allow 5 to 7 waves per SIMD)

@@ -247,6 +247,47 @@ def test_cost_v3_short_rows_in_groups(gpu, Q, T, C, B, integer, pmove):
         assert all(_close(again[b], got[b], integer, nterms) for b in range(B)), (again, got)
 
 
+SHORT_ROWS_QUADS = [  # Q, T, C, B, integer weights, pmove: short rows, an LDS table indexed by packed core pairs, 64 partitions or more
+    (9, 700, 8, 64, True, 0.5), (30, 333, 16, 67, False, 0.3), (40, 6100, 20, 65, True, 0.2), (70, 150, 64, 130, False, 0.9),
+    (128, 77, 100, 64, True, 0.5), (260, 1300, 60, 66, False, 0.1), (500, 64, 130, 70, True, 1.0), (512, 3, 16, 64, False, 1.0),
+    (63, 498, 64, 301, False, 1.0), (18, 138, 16, 9000, False, 0.05), (33, 1, 8, 64, True, 1.0), (33, 2, 8, 66, False, 1.0),
+]
+
+
+@pytest.mark.parametrize("Q,T,C,B,integer,pmove", SHORT_ROWS_QUADS)
+def test_cost_v3_short_rows_four_partitions(gpu, Q, T, C, B, integer, pmove):
+    """Rows of at most 512 bytes, from 64 partitions on, a table that sits in LDS indexed by packed core pairs (up to
+    16 cores, up to 64 cores, 16-bit tables of more): a wave step takes the rows of four consecutive partitions
+    (interleaved strip words, one look-up per byte lane); B is not always a multiple of four, rows are ragged, items
+    are parts of a partition (6100 slices) or several quads (9000 partitions of 138 slices).  Every partition against
+    the vectorised CPU sum, and against the same partitions in batches too small for this form."""
+    from oracle.cpu_variants import NumpyCost
+    torch, engine, eng, dev = gpu
+    ir, eu, ev, w, rng = _random_setup(Q, T, C, integer, seed=Q * 19 + T)
+    D = engine.apsp(C, eu, ev, w)
+    dc, dt = engine.DeviceCircuit(ir, dev), engine.DistanceTable(D, dev)
+    assert (dt.kind == engine.QP_DT_U16) == integer
+    assert dc.ldq <= 512 and dc.c.group_ldq == dc.ldq and dc.c.group_sched
+    Tp = ir.T + (1 if Q % 2 else 0)
+    A = np.empty((B, Tp, dc.ldq), np.uint8)
+    A[:, 0] = rng.integers(0, C, size=(B, dc.ldq), dtype=np.uint8)
+    for t in range(1, Tp):
+        move = rng.random((B, dc.ldq)) < pmove
+        A[:, t] = np.where(move, rng.integers(0, C, size=(B, dc.ldq), dtype=np.uint8), A[:, t - 1])
+    A[:, :, Q:] = rng.integers(0, 256, size=(B, Tp, dc.ldq - Q), dtype=np.uint8)  # pad bytes are garbage
+    A[1, 1:] = A[1, :1]  # one partition that never moves
+    Ad = torch.from_numpy(A).to(dev)
+    got = eng.cost_v3(dc, dt, Ad, table="table").cpu().numpy()
+    assert got.tobytes() == eng.cost_v3(dc, dt, Ad, table="table").cpu().numpy().tobytes()
+    nc = NumpyCost(ir.slices, ir.gate_q, ir.gate_mr, D)
+    nterms = ir.nE + ir.T * Q
+    for b in list(range(min(B, 140))) + list(range(max(0, B - 9), B)):
+        want = nc.cost(A[b, :ir.T, :Q])
+        assert _close(got[b], want, integer, nterms), (b, got[b], want)
+    small = torch.cat([eng.cost_v3(dc, dt, Ad[i:i + 60].contiguous(), table="table") for i in range(0, min(B, 600), 60)]).cpu().numpy()
+    assert all(_close(small[b], got[b], integer, nterms) for b in range(len(small))), (small, got)
+
+
 @pytest.mark.parametrize("Q,T,C,B,integer", [(18, 40, 16, 50001, False), (100, 70, 64, 26001, True), (40, 300, 9, 25000, True)])
 def test_cost_v3_many_short_partitions(gpu, Q, T, C, B, integer):
     """Tens of thousands of partitions of a circuit of few steps: a wave then walks several consecutive partitions
@@ -264,7 +305,10 @@ def test_cost_v3_many_short_partitions(gpu, Q, T, C, B, integer):
     for t in range(1, ir.T):
         A[:, t] = torch.where(keep[:, t], A[:, t - 1], A[:, t])
     got = eng.cost_v3(dc, dt, A).cpu().numpy()
-    small = torch.cat([eng.cost_v3(dc, dt, A[i:i + 1000].contiguous()) for i in range(0, B, 1000)]).cpu().numpy()
+    # (the last batch takes the odd partition along: fewer than 64 partitions take another kernel, whose fp64 sums
+    # round in another order)
+    starts = list(range(0, B - 999, 1000))
+    small = torch.cat([eng.cost_v3(dc, dt, A[i:(i + 1000 if i != starts[-1] else B)].contiguous()) for i in starts]).cpu().numpy()
     assert got.tobytes() == small.tobytes()
     nc = NumpyCost(ir.slices, ir.gate_q, ir.gate_mr, D)
     for b in list(range(5)) + [int(x) for x in rng.integers(0, B, size=40)] + [B - 1]:
