@@ -12,7 +12,7 @@
 #include "qplace_internal.h"
 
 #ifndef QP_GROUPS4_AHEAD
-#define QP_GROUPS4_AHEAD 2
+#define QP_GROUPS4_AHEAD 1
 #endif
 
 namespace {
@@ -635,8 +635,10 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void k_cost_v3_gro
 // Strip of a wave: [row before][G rows] of words; a lane's sixteen words go out as four 16-byte writes whose
 // quarters are permuted between lane pairs (word index i sits at i ^ (((i >> 5) & 3) << 2), indices counted from
 // the first of the G rows, negative in the row before), so that the eight lanes of an LDS pass hit all 32 banks.
-// Items: as in k_cost_v3_groups with a quad of partitions in the place of a partition; a last quad that is not
-// full repeats the batch's last partition and drops the copies.
+// Work: the steps of all quads form one stream, cut into runs the waves take in turn (see the launcher); a run that
+// starts inside a partition loads the row before its first, one that ends inside writes a partial sum, and
+// k_sum_parts adds a quad's parts in run order.  A last quad that is not full repeats the batch's last partition and
+// drops the copies.  Sixteen waves per CU (two workgroups, 128 registers): fewer waves and deeper prefetch both lose.
 constexpr int kGroups4Threads = 512;
 constexpr int kGroups4Ahead = QP_GROUPS4_AHEAD;
 
@@ -693,185 +695,223 @@ __global__ __launch_bounds__(kGroups4Threads, 4) void k_cost_v3_groups4(V3Args p
 
     const uint32_t* gsched_lane = p.gsched + lane;
     const size_t pstride = (size_t)p.Tp * ldq;
-    for (int64_t it = (int64_t)blockIdx.x * kWaves + wave; it < p.nitems; it += (int64_t)gridDim.x * kWaves) {
-        // an item: a run of whole groups of slices (rows r0 .. r1 - 1) of nq consecutive quads of partitions; nq > 1
-        // only when the run is the whole circuit, and the wave then walks the quads as one stream of steps
-        const int chunk = (int)(it / p.nbgroups);
-        const int64_t b0 = (it - (int64_t)chunk * p.nbgroups) * p.parts_per_item * 4;
-        const int nq = (int)min((int64_t)p.parts_per_item, (p.B - b0 + 3) / 4);
-        const int r0 = chunk * p.rows_per_item;  // a multiple of G
-        const int r1 = min(p.T, r0 + p.rows_per_item);
-        const int nsteps = (r1 - r0 + G - 1) / G;
-        const int j0 = r0 / G;
-        const int N = nq * nsteps;
-        Acc acc[4] = {0, 0, 0, 0};
+    // The stream of steps (quad 0 step 0, quad 0 step 1, ..., quad 1 step 0, ...) is cut into p.nbgroups runs of equal
+    // length (to within one unit of `gran` steps); the waves of the launch take the runs in turn.
+    const int ns = (p.T + G - 1) / G;  // steps of a partition
+    const int gran = p.parts_per_item;  // 1, or ns: runs are then whole quads
+    const int64_t R = p.nbgroups;
+    for (int64_t run = (int64_t)blockIdx.x * kWaves + wave; run < R; run += (int64_t)gridDim.x * kWaves) {
+    const int64_t n_begin = (run * p.nitems / R) * gran, n_end = ((run + 1) * p.nitems / R) * gran;
+    if (n_begin >= n_end) continue;
+    // the part of quad q this run sums is number (run - first run with a step of q) of the quad's parts
+    auto part_of = [&](int64_t q) -> int64_t {
+        if (gran != 1) return 0;
+        return run - (((q * ns + 1) * R - 1) / p.nitems);
+    };
+    const int64_t N = n_end - n_begin;
+    int64_t cq = n_begin / ns;            // the step being worked on: quad cq, step s
+    int s = (int)(n_begin - cq * ns);
+    Acc acc[4] = {0, 0, 0, 0};
+    double tot[4] = {0.0, 0.0, 0.0, 0.0};  // 16-bit tables: what acc held when it was last emptied (every 256 steps)
+    int since = 0;
 
-        // one look-up per partition: the byte lanes of (from, to) are the partitions
-        auto look4 = [&](uint32_t from, uint32_t to) {
-            if constexpr (TABMODE == kTabLds256) {
-                E e0, e1, e2, e3;
-                entries_at_halves<E>(__builtin_amdgcn_perm(from, to, 0x05010400u), tbase, e0, e1);
-                entries_at_halves<E>(__builtin_amdgcn_perm(from, to, 0x07030602u), tbase, e2, e3);
-                acc[0] += (Acc)e0;
-                acc[1] += (Acc)e1;
-                acc[2] += (Acc)e2;
-                acc[3] += (Acc)e3;
-            } else {
-                RepE e0, e1, e2, e3;
-                if constexpr (TABMODE == kTabLdsRep4) {
-                    const uint32_t k = (from << 4) | to;  // from << 4 | to, a byte each
-                    rep_at_halves(__builtin_amdgcn_perm(0u, k, 0x0c010c00u), e0, e1);
-                    rep_at_halves(__builtin_amdgcn_perm(0u, k, 0x0c030c02u), e2, e3);
-                } else {  // ids times four: with the source ids shifted back a half is four times from << 6 | to
-                    const uint32_t f = from >> 2;
-                    rep_at_halves(__builtin_amdgcn_perm(f, to, 0x05010400u), e0, e1);
-                    rep_at_halves(__builtin_amdgcn_perm(f, to, 0x07030602u), e2, e3);
-                }
-                acc[0] += (Acc)e0;
-                acc[1] += (Acc)e1;
-                acc[2] += (Acc)e2;
-                acc[3] += (Acc)e3;
+    // one look-up per partition: the byte lanes of (from, to) are the partitions
+    auto look4 = [&](uint32_t from, uint32_t to) {
+        if constexpr (TABMODE == kTabLds256) {
+            E e0, e1, e2, e3;
+            entries_at_halves<E>(__builtin_amdgcn_perm(from, to, 0x05010400u), tbase, e0, e1);
+            entries_at_halves<E>(__builtin_amdgcn_perm(from, to, 0x07030602u), tbase, e2, e3);
+            acc[0] += (Acc)e0;
+            acc[1] += (Acc)e1;
+            acc[2] += (Acc)e2;
+            acc[3] += (Acc)e3;
+        } else {
+            RepE e0, e1, e2, e3;
+            if constexpr (TABMODE == kTabLdsRep4) {
+                const uint32_t k = (from << 4) | to;  // from << 4 | to, a byte each
+                rep_at_halves(__builtin_amdgcn_perm(0u, k, 0x0c010c00u), e0, e1);
+                rep_at_halves(__builtin_amdgcn_perm(0u, k, 0x0c030c02u), e2, e3);
+            } else {  // ids times four: with the source ids shifted back a half is four times from << 6 | to
+                const uint32_t f = from >> 2;
+                rep_at_halves(__builtin_amdgcn_perm(f, to, 0x05010400u), e0, e1);
+                rep_at_halves(__builtin_amdgcn_perm(f, to, 0x07030602u), e2, e3);
             }
-        };
-        // word w of the four partitions' pieces -> the words of qubits 4w .. 4w + 3 (4 x 4 byte transposes)
-        auto interleave = [&](const uint4 (&x)[4], uint32_t (&o)[16]) {
-            const uint32_t xw[4][4] = {{x[0].x, x[0].y, x[0].z, x[0].w}, {x[1].x, x[1].y, x[1].z, x[1].w},
-                                       {x[2].x, x[2].y, x[2].z, x[2].w}, {x[3].x, x[3].y, x[3].z, x[3].w}};
+            acc[0] += (Acc)e0;
+            acc[1] += (Acc)e1;
+            acc[2] += (Acc)e2;
+            acc[3] += (Acc)e3;
+        }
+    };
+    // word w of the four partitions' pieces -> the words of qubits 4w .. 4w + 3 (4 x 4 byte transposes)
+    auto interleave = [&](const uint4 (&x)[4], uint32_t (&o)[16]) {
+        const uint32_t xw[4][4] = {{x[0].x, x[0].y, x[0].z, x[0].w}, {x[1].x, x[1].y, x[1].z, x[1].w},
+                                   {x[2].x, x[2].y, x[2].z, x[2].w}, {x[3].x, x[3].y, x[3].z, x[3].w}};
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const uint32_t t01a = __builtin_amdgcn_perm(xw[1][w], xw[0][w], 0x05010400u);  // a0 b0 a1 b1
-                const uint32_t t01b = __builtin_amdgcn_perm(xw[1][w], xw[0][w], 0x07030602u);  // a2 b2 a3 b3
-                const uint32_t t23a = __builtin_amdgcn_perm(xw[3][w], xw[2][w], 0x05010400u);  // c0 d0 c1 d1
-                const uint32_t t23b = __builtin_amdgcn_perm(xw[3][w], xw[2][w], 0x07030602u);
-                o[4 * w + 0] = __builtin_amdgcn_perm(t23a, t01a, 0x05040100u);  // a0 b0 c0 d0
-                o[4 * w + 1] = __builtin_amdgcn_perm(t23a, t01a, 0x07060302u);
-                o[4 * w + 2] = __builtin_amdgcn_perm(t23b, t01b, 0x05040100u);
-                o[4 * w + 3] = __builtin_amdgcn_perm(t23b, t01b, 0x07060302u);
-            }
-        };
-        auto park = [&](const uint32_t (&o)[16], int piece) {
+        for (int w = 0; w < 4; ++w) {
+            const uint32_t t01a = __builtin_amdgcn_perm(xw[1][w], xw[0][w], 0x05010400u);  // a0 b0 a1 b1
+            const uint32_t t01b = __builtin_amdgcn_perm(xw[1][w], xw[0][w], 0x07030602u);  // a2 b2 a3 b3
+            const uint32_t t23a = __builtin_amdgcn_perm(xw[3][w], xw[2][w], 0x05010400u);  // c0 d0 c1 d1
+            const uint32_t t23b = __builtin_amdgcn_perm(xw[3][w], xw[2][w], 0x07030602u);
+            o[4 * w + 0] = __builtin_amdgcn_perm(t23a, t01a, 0x05040100u);  // a0 b0 c0 d0
+            o[4 * w + 1] = __builtin_amdgcn_perm(t23a, t01a, 0x07060302u);
+            o[4 * w + 2] = __builtin_amdgcn_perm(t23b, t01b, 0x05040100u);
+            o[4 * w + 3] = __builtin_amdgcn_perm(t23b, t01b, 0x07060302u);
+        }
+    };
+    auto park = [&](const uint32_t (&o)[16], int piece) {
 #pragma unroll
-            for (int w = 0; w < 4; ++w)
-                *reinterpret_cast<uint4*>(rows + quarter(piece, w)) = make_uint4(o[4 * w], o[4 * w + 1], o[4 * w + 2], o[4 * w + 3]);
-        };
-        // both endpoints of a packed gate word, for the four partitions
-        auto endpoints = [&](uint32_t g, uint32_t& u4, uint32_t& v4) {
-            const uint32_t x = g ^ ((g >> 3) & 0x000C000Cu);
-            uint32_t a0, a1;
-            asm("v_mad_u32_u16 %0, %1, 4, %2 op_sel:[0,0,0,0]" : "=v"(a0) : "v"(x), "s"(rbase));
-            asm("v_mad_u32_u16 %0, %1, 4, %2 op_sel:[1,0,0,0]" : "=v"(a1) : "v"(x), "s"(rbase));
-            u4 = *(lds_u32*)(uintptr_t)a0;
-            v4 = *(lds_u32*)(uintptr_t)a1;
-        };
+        for (int w = 0; w < 4; ++w)
+            *reinterpret_cast<uint4*>(rows + quarter(piece, w)) = make_uint4(o[4 * w], o[4 * w + 1], o[4 * w + 2], o[4 * w + 3]);
+    };
+    // both endpoints of a packed gate word, for the four partitions
+    auto endpoints = [&](uint32_t g, uint32_t& u4, uint32_t& v4) {
+        const uint32_t x = g ^ ((g >> 3) & 0x000C000Cu);
+        uint32_t a0, a1;
+        asm("v_mad_u32_u16 %0, %1, 4, %2 op_sel:[0,0,0,0]" : "=v"(a0) : "v"(x), "s"(rbase));
+        asm("v_mad_u32_u16 %0, %1, 4, %2 op_sel:[1,0,0,0]" : "=v"(a1) : "v"(x), "s"(rbase));
+        u4 = *(lds_u32*)(uintptr_t)a0;
+        v4 = *(lds_u32*)(uintptr_t)a1;
+    };
+    auto part_base = [&](int64_t q, int g) { return p.A + (size_t)min(4 * q + g, p.B - 1) * pstride; };  // wave-uniform
 
-        // the next step of the stream (quad fq, step fs): the lane's piece of its rows in the four partitions (rows
-        // past the run's end repeat its last row, never counted) and the first gate chunks of its group; past the
-        // end of the stream the last step is requested again
-        int fq = 0, fs = 0;
-        auto fetch_next = [&](uint4 (&rslot)[4], uint32_t (&gslot)[kRowEdgeChunks]) {
-            const int rowl = min(r0 + fs * G + lrow, r1 - 1);
-            const uint32_t off = (uint32_t)rowl * (uint32_t)ldq + (uint32_t)lq0;
+    // the next step of the stream (quad fq, step fs): the lane's piece of its rows in the four partitions (rows
+    // past the circuit's end repeat its last row, never counted) and the first gate chunks of its group; past the
+    // end of this wave's part the last step is requested again
+    int64_t fq = cq, fleft = N;
+    int fs = s;
+    auto fetch_next = [&](uint4 (&rslot)[4], uint32_t (&gslot)[kRowEdgeChunks]) {
+        const int rowl = min(fs * G + lrow, p.T - 1);
+        const uint32_t off = (uint32_t)rowl * (uint32_t)ldq + (uint32_t)lq0;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int64_t b = min(b0 + 4 * (int64_t)fq + g, p.B - 1);  // wave-uniform
-                rslot[g] = load_row16(p.A + (size_t)b * pstride + off);  // (raw: ids() is applied when the step is worked on)
-            }
-            const uint32_t* gp = gsched_lane + p.gptr[j0 + fs];
+        for (int g = 0; g < 4; ++g) rslot[g] = load_row16(part_base(fq, g) + off);  // (raw: ids() is applied when the step is worked on)
+        const uint32_t* gp = gsched_lane + p.gptr[fs];
 #pragma unroll
-            for (int c = 0; c < kRowEdgeChunks; ++c) gslot[c] = gp[c * kWave];
-            if (fs + 1 < nsteps) {
-                ++fs;
-            } else if (fq + 1 < nq) {
+        for (int c = 0; c < kRowEdgeChunks; ++c) gslot[c] = gp[c * kWave];
+        if (fleft > 1) {
+            --fleft;
+            if (++fs == ns) {
                 fs = 0;
                 ++fq;
             }
-        };
-
-        if (r0 >= 1 && lane < lpr) {  // the row before the run (nq == 1 here)
-            uint4 x[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                x[g] = ids(*reinterpret_cast<const uint4*>(p.A + (size_t)min(b0 + g, p.B - 1) * pstride + (size_t)(r0 - 1) * ldq + lane * 16));
-            uint32_t o[16];
-            interleave(x, o);
-            park(o, lane * 16 - ldq);
         }
-        uint4 ring[AHEAD][4];
-        uint32_t gring[AHEAD][kRowEdgeChunks];
-#pragma unroll
-        for (int k = 0; k < AHEAD; ++k) fetch_next(ring[k], gring[k]);
+    };
 
-        int cq = 0, s = 0;  // the step being worked on: quad cq of the item, step s
-        for (int n0 = 0; n0 < N; n0 += AHEAD) {
+    if (s >= 1 && lane < lpr) {  // the part starts inside a partition: the row before its first
+        uint4 x[4];
 #pragma unroll
-            for (int k = 0; k < AHEAD; ++k) {
-                if (n0 + k >= N) break;
-                uint32_t cur[16], gates[kRowEdgeChunks];
-                {
-                    const uint4 x[4] = {ids(ring[k][0]), ids(ring[k][1]), ids(ring[k][2]), ids(ring[k][3])};
-                    interleave(x, cur);
-                }
+        for (int g = 0; g < 4; ++g)
+            x[g] = ids(*reinterpret_cast<const uint4*>(part_base(cq, g) + (size_t)(s * G - 1) * ldq + lane * 16));
+        uint32_t o[16];
+        interleave(x, o);
+        park(o, lane * 16 - ldq);
+    }
+    uint4 ring[AHEAD][4];
+    uint32_t gring[AHEAD][kRowEdgeChunks];
 #pragma unroll
-                for (int c = 0; c < kRowEdgeChunks; ++c) gates[c] = gring[k][c];
-                fetch_next(ring[k], gring[k]);
+    for (int k = 0; k < AHEAD; ++k) fetch_next(ring[k], gring[k]);
 
-                if (lane_on) park(cur, lane_off);
-                const int w0 = p.gptr[j0 + s];
-                const int nch = (p.gptr[j0 + s + 1] - w0) / kWave;
-                uint32_t U[kRowEdgeChunks], V[kRowEdgeChunks];
+    for (int64_t n0 = 0; n0 < N; n0 += AHEAD) {
 #pragma unroll
-                for (int c = 0; c < kRowEdgeChunks; ++c) endpoints(c < nch ? gates[c] : 0u, U[c], V[c]);  // a chunk the group lacks: one word twice
-                // movement: rows 2 .. r1 - 1, row before -> this row, two qubits at a time (the look-ups of a pair
-                // are in flight together; a qubit that stayed looks up the zero diagonal)
-                const int row = r0 + s * G + lrow;
-                const bool mv = lane_on && row >= 2 && row < r1;
-                const int before = lane_off - ldq;  // the same piece one row earlier
-                uint32_t prv[16];
+        for (int k = 0; k < AHEAD; ++k) {
+            if (n0 + k >= N) break;
+            uint32_t cur[16], gates[kRowEdgeChunks];
+            {
+                const uint4 x[4] = {ids(ring[k][0]), ids(ring[k][1]), ids(ring[k][2]), ids(ring[k][3])};
+                interleave(x, cur);
+            }
 #pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const uint4 v = *reinterpret_cast<const uint4*>(rows + quarter(before, w));
-                    prv[4 * w] = v.x;
-                    prv[4 * w + 1] = v.y;
-                    prv[4 * w + 2] = v.z;
-                    prv[4 * w + 3] = v.w;
-                }
-                // the group's last row is "the row before" of the next step (after every lane has read its own)
-                if (last_row) park(cur, lq0 - ldq);
+            for (int c = 0; c < kRowEdgeChunks; ++c) gates[c] = gring[k][c];
+            fetch_next(ring[k], gring[k]);
+
+            if (lane_on) park(cur, lane_off);
+            const int w0 = p.gptr[s];
+            const int nch = (p.gptr[s + 1] - w0) / kWave;
+            uint32_t U[kRowEdgeChunks], V[kRowEdgeChunks];
 #pragma unroll
-                for (int j = 0; j < 16; j += 2) {
-                    if (mv && ((prv[j] ^ cur[j]) | (prv[j + 1] ^ cur[j + 1])) != 0) {
-                        look4(prv[j], cur[j]);
-                        look4(prv[j + 1], cur[j + 1]);
-                    }
-                }
+            for (int c = 0; c < kRowEdgeChunks; ++c) endpoints(c < nch ? gates[c] : 0u, U[c], V[c]);  // a chunk the group lacks: one word twice
+            // movement: rows 2 .. T - 1, row before -> this row, two qubits at a time (the look-ups of a pair
+            // are in flight together; a qubit that stayed looks up the zero diagonal)
+            const int row = s * G + lrow;
+            const bool mv = lane_on && row >= 2 && row < p.T;
+            const int before = lane_off - ldq;  // the same piece one row earlier
+            uint32_t prv[16];
 #pragma unroll
-                for (int c = 0; c < kRowEdgeChunks; c += 2) {
-                    if (((U[c] ^ V[c]) | (U[c + 1] ^ V[c + 1])) != 0) {
-                        look4(U[c], V[c]);
-                        look4(U[c + 1], V[c + 1]);
-                    }
+            for (int w = 0; w < 4; ++w) {
+                const uint4 v = *reinterpret_cast<const uint4*>(rows + quarter(before, w));
+                prv[4 * w] = v.x;
+                prv[4 * w + 1] = v.y;
+                prv[4 * w + 2] = v.z;
+                prv[4 * w + 3] = v.w;
+            }
+            // the group's last row is "the row before" of the next step (after every lane has read its own)
+            if (last_row) park(cur, lq0 - ldq);
+#pragma unroll
+            for (int j = 0; j < 16; j += 2) {
+                if (mv && ((prv[j] ^ cur[j]) | (prv[j + 1] ^ cur[j + 1])) != 0) {
+                    look4(prv[j], cur[j]);
+                    look4(prv[j + 1], cur[j + 1]);
                 }
-                for (int c = kRowEdgeChunks; c < nch; ++c) {
-                    uint32_t u4, v4;
-                    endpoints(gsched_lane[w0 + c * kWave], u4, v4);
-                    if (u4 != v4) look4(u4, v4);
+            }
+#pragma unroll
+            for (int c = 0; c < kRowEdgeChunks; c += 2) {
+                if (((U[c] ^ V[c]) | (U[c + 1] ^ V[c + 1])) != 0) {
+                    look4(U[c], V[c]);
+                    look4(U[c + 1], V[c + 1]);
                 }
-                if (s + 1 < nsteps) {
-                    ++s;
-                } else {  // the quad's run is done: its four sums, and a fresh start for the next quad
+            }
+            for (int c = kRowEdgeChunks; c < nch; ++c) {
+                uint32_t u4, v4;
+                endpoints(gsched_lane[w0 + c * kWave], u4, v4);
+                if (u4 != v4) look4(u4, v4);
+            }
+            if constexpr (KIND == QP_DT_U16) {  // a lane's 32-bit sum holds 256 steps of 16-bit entries
+                if (++since == 256) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const double sum = wave_sum(acc[g]);
-                        const int64_t b = b0 + 4 * (int64_t)cq + g;
-                        if (lane == 0 && b < p.B) p.partial[(size_t)chunk * p.B + b] = sum;
+                        tot[g] += (double)acc[g];
                         acc[g] = 0;
                     }
-                    s = 0;
-                    ++cq;
+                    since = 0;
                 }
+            }
+            const bool part_done = n0 + k + 1 == N;
+            if (s + 1 < ns && !part_done) {
+                ++s;
+            } else {  // the quad (or this wave's part of it) is done: its four sums, and a fresh start
+                const int64_t slot = part_of(cq);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    double sum;
+                    if constexpr (KIND == QP_DT_U16) sum = wave_sum(tot[g] + (double)acc[g]);
+                    else sum = wave_sum(acc[g]);
+                    const int64_t b = 4 * cq + g;
+                    if (lane == 0 && b < p.B) p.partial[(size_t)slot * p.B + b] = sum;
+                    acc[g] = 0;
+                    tot[g] = 0.0;
+                }
+                since = 0;
+                s = 0;
+                ++cq;
             }
         }
     }
+    }  // runs
+}
+
+// out[b] = the sum of the parts k_cost_v3_groups4 wrote for partition b's quad, in the order of the waves that wrote
+// them: the quad's steps n .. n + ns - 1 of the stream lie in runs first .. last (W runs, `units` steps).
+__global__ void k_sum_parts(const double* partial, int64_t B, int64_t W, int64_t units, int32_t ns, int32_t gran, double* out) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int64_t nparts = 1;
+    if (gran == 1) {
+        const int64_t q = b / 4;
+        const int64_t first = ((q * ns + 1) * W - 1) / units, last = (((q + 1) * ns) * W - 1) / units;
+        nparts = last - first + 1;
+    }
+    double s = 0.0;
+    for (int64_t c = 0; c < nparts; ++c) s += partial[(size_t)c * B + b];
+    out[b] = s;
 }
 
 // Rows longer than 512 bytes (one row per wave step).  Differences from k_cost_v3: the previous row
@@ -3177,17 +3217,13 @@ int slice_cost_v3_impl(const char* fn, const QpCircuit* circ, const QpDTable* dt
             const size_t strips4 = (size_t)(kGroups4Threads / kWave) * (G + 1) * ldq * 4;
             if (!one_row_groups && B >= 64 && (mode == kTabLdsRep4 || mode == kTabLdsRep6 || mode == kTabLds256) &&
                 tab_lds + strips4 <= (size_t)kLdsBytes) {
+                // The stream of (quad, step) is cut into runs: one per wave of the launch (all resident, every wave the
+                // same number of steps to within one) when a partition has more than 16 steps -- a quad is then summed in
+                // parts, at most kParts4 of them (fewer runs if need be) -- else runs of a few whole quads.
                 const int64_t nquads = (B + 3) / 4;
-                const int64_t want4 = steps_total * nquads / ((int64_t)cus * 16 * 4);
-                const int64_t spi4 = std::min<int64_t>(steps_total, std::min<int64_t>(256, std::max<int64_t>(8, want4)));
-                q.rows_per_item = (int)(spi4 * G);
-                const int32_t chunks4 = (T + q.rows_per_item - 1) / q.rows_per_item;
-                q.parts_per_item = 1;  // in quads
-                if (chunks4 == 1)
-                    q.parts_per_item = (int)std::max<int64_t>(1, std::min<int64_t>({256 / steps_total, 16, nquads / ((int64_t)cus * 16 * 2)}));
-                q.nbgroups = (nquads + q.parts_per_item - 1) / q.parts_per_item;
-                q.nitems = (int64_t)chunks4 * q.nbgroups;
-                if (int rc = need_workspace((size_t)chunks4 * B * sizeof(double))) return rc;
+                const bool whole = steps_total <= 16;
+                q.parts_per_item = whole ? (int)steps_total : 1;
+                q.nitems = whole ? nquads : nquads * steps_total;
                 void (*kern4)(V3Args) = nullptr;
 #define QP_GROUPS4(MODE) (dt->kind == QP_DT_F64 ? k_cost_v3_groups4<QP_DT_F64, MODE, kGroups4Ahead> : k_cost_v3_groups4<QP_DT_U16, MODE, kGroups4Ahead>)
                 kern4 = mode == kTabLdsRep4 ? QP_GROUPS4(kTabLdsRep4) : mode == kTabLdsRep6 ? QP_GROUPS4(kTabLdsRep6) : QP_GROUPS4(kTabLds256);
@@ -3197,10 +3233,21 @@ int slice_cost_v3_impl(const char* fn, const QpCircuit* circ, const QpDTable* dt
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
                 int per_cu4 = 1;
                 HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu4, reinterpret_cast<const void*>(kern4), kGroups4Threads, lds4));
-                const unsigned grid4 = (unsigned)std::min<int64_t>((int64_t)cus * std::max(per_cu4, 1), (q.nitems + waves4 - 1) / waves4);
-                kern4<<<grid4, kGroups4Threads, lds4, stream>>>(q);
+                constexpr int64_t kParts4 = 8;  // a quad's steps lie in at most this many runs
+                const int64_t grid4 = std::min<int64_t>((int64_t)cus * std::max(per_cu4, 1), (q.nitems + waves4 - 1) / waves4);
+                if (whole) {
+                    // runs of a few quads, taken in turn (measured: faster than one run per wave; 3 quads for 120 000
+                    // partitions of 5 steps)
+                    const int64_t ppi = std::max<int64_t>(1, std::min<int64_t>({256 / steps_total, 16, nquads / ((int64_t)cus * 16 * 2)}));
+                    q.nbgroups = (nquads + ppi - 1) / ppi;
+                } else {
+                    q.nbgroups = std::max<int64_t>(1, std::min<int64_t>(grid4 * waves4, nquads * (kParts4 - 2)));
+                }
+                const int64_t nparts = whole ? 1 : kParts4;
+                if (int rc = need_workspace((size_t)nparts * B * sizeof(double))) return rc;
+                kern4<<<(unsigned)grid4, kGroups4Threads, lds4, stream>>>(q);
                 HIP_TRY(hipGetLastError());
-                k_sum_chunks<<<(unsigned)((B + 255) / 256), 256, 0, stream>>>(q.partial, B, chunks4, out);
+                k_sum_parts<<<(unsigned)((B + 255) / 256), 256, 0, stream>>>(q.partial, B, q.nbgroups, q.nitems, (int32_t)steps_total, q.parts_per_item, out);
                 HIP_TRY(hipGetLastError());
                 return QP_OK;
             }
