@@ -3219,7 +3219,7 @@ int slice_cost_v3_impl(const char* fn, const QpCircuit* circ, const QpDTable* dt
                 tab_lds + strips4 <= (size_t)kLdsBytes) {
                 // The stream of (quad, step) is cut into runs: one per wave of the launch (all resident, every wave the
                 // same number of steps to within one) when a partition has more than 16 steps -- a quad is then summed in
-                // parts, at most kParts4 of them (fewer runs if need be) -- else runs of a few whole quads.
+                // parts -- else runs of a few whole quads.
                 const int64_t nquads = (B + 3) / 4;
                 const bool whole = steps_total <= 16;
                 q.parts_per_item = whole ? (int)steps_total : 1;
@@ -3233,17 +3233,20 @@ int slice_cost_v3_impl(const char* fn, const QpCircuit* circ, const QpDTable* dt
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
                 int per_cu4 = 1;
                 HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu4, reinterpret_cast<const void*>(kern4), kGroups4Threads, lds4));
-                constexpr int64_t kParts4 = 8;  // a quad's steps lie in at most this many runs
                 const int64_t grid4 = std::min<int64_t>((int64_t)cus * std::max(per_cu4, 1), (q.nitems + waves4 - 1) / waves4);
+                int64_t nparts = 1;  // a quad's steps lie in at most this many runs
                 if (whole) {
                     // runs of a few quads, taken in turn (measured: faster than one run per wave; 3 quads for 120 000
                     // partitions of 5 steps)
                     const int64_t ppi = std::max<int64_t>(1, std::min<int64_t>({256 / steps_total, 16, nquads / ((int64_t)cus * 16 * 2)}));
                     q.nbgroups = (nquads + ppi - 1) / ppi;
                 } else {
-                    q.nbgroups = std::max<int64_t>(1, std::min<int64_t>(grid4 * waves4, nquads * (kParts4 - 2)));
+                    // R runs over nquads * steps_total steps: fewer than R / nquads + 1 run boundaries inside a quad.  As many
+                    // parts as a run per wave needs, within what qp_slice_cost_workspace promises for every batch.
+                    const int64_t waves_all = grid4 * waves4;
+                    nparts = std::min<int64_t>(4 * ((T + 15) / 16 + 1), std::max<int64_t>(3, (waves_all + nquads - 1) / nquads + 2));
+                    q.nbgroups = std::max<int64_t>(1, std::min<int64_t>(waves_all, nquads * (nparts - 2)));
                 }
-                const int64_t nparts = whole ? 1 : kParts4;
                 if (int rc = need_workspace((size_t)nparts * B * sizeof(double))) return rc;
                 kern4<<<(unsigned)grid4, kGroups4Threads, lds4, stream>>>(q);
                 HIP_TRY(hipGetLastError());
