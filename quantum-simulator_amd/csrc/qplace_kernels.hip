@@ -3245,7 +3245,8 @@ int slice_cost_v3_impl(const char* fn, const QpCircuit* circ, const QpDTable* dt
                     // parts as a run per wave needs, within what qp_slice_cost_workspace promises for every batch.
                     const int64_t waves_all = grid4 * waves4;
                     nparts = std::min<int64_t>(4 * ((T + 15) / 16 + 1), std::max<int64_t>(3, (waves_all + nquads - 1) / nquads + 2));
-                    q.nbgroups = std::max<int64_t>(1, std::min<int64_t>(waves_all, nquads * (nparts - 2)));
+                    // (never more runs than steps: a run without a step would leave its part of a quad unwritten)
+                    q.nbgroups = std::max<int64_t>(1, std::min<int64_t>({waves_all, nquads * (nparts - 2), q.nitems}));
                 }
                 if (int rc = need_workspace((size_t)nparts * B * sizeof(double))) return rc;
                 kern4<<<(unsigned)grid4, kGroups4Threads, lds4, stream>>>(q);

@@ -251,6 +251,8 @@ SHORT_ROWS_QUADS = [  # Q, T, C, B, integer weights, pmove: short rows, an LDS t
     (9, 700, 8, 64, True, 0.5), (30, 333, 16, 67, False, 0.3), (40, 6100, 20, 65, True, 0.2), (70, 150, 64, 130, False, 0.9),
     (128, 77, 100, 64, True, 0.5), (260, 1300, 60, 66, False, 0.1), (500, 64, 130, 70, True, 1.0), (512, 3, 16, 64, False, 1.0),
     (63, 498, 64, 301, False, 1.0), (18, 138, 16, 9000, False, 0.05), (33, 1, 8, 64, True, 1.0), (33, 2, 8, 66, False, 1.0),
+    # fewer steps in the whole batch than the GPU holds waves (a run per step, none without one)
+    (195, 73, 33, 386, False, 1.0), (97, 1080, 2, 76, False, 1.0), (8, 6202, 48, 83, True, 0.02),
 ]
 
 

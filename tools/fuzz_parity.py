@@ -124,9 +124,17 @@ def main():
         return [pick(2, 80), pick(81, 512), pick(513, 1024), pick(1025, 1600)][pick(0, 3)]
 
     def draw():
-        kind = pick(0, 13)
+        kind = pick(0, 14)
         if os.environ.get("QP_FUZZ_KIND"):  # one kind of case only
             kind = int(os.environ["QP_FUZZ_KIND"])
+        if kind == 14:  # rows of at most 512 bytes, 64 partitions or more: four partitions per wave step, runs of steps or of quads
+            Q = pick(2, 512)
+            ldq = (Q + 15) // 16 * 16
+            T = pick(1, max(1, min(9000, 300000 // ldq)))
+            integer = bool(pick(0, 1))
+            C = pick(2, 256) if integer else pick(2, 64)
+            B = pick(64, 200) if T * ldq > 60000 else pick(64, 3000)
+            return "cost_v3_short_rows_quads", TC.test_cost_v3_short_rows_four_partitions, (gpu, Q, T, C, B, integer, float(rng.choice([0.02, 0.3, 1.0])))
         if kind == 13:  # communication counts from the pair counters of the row walk: whole partitions or chunks
             B = pick(50, 63) if pick(0, 2) == 0 else pick(64, 500)
             T = pick(16384 // B + 1, 16384 // B + 60)
