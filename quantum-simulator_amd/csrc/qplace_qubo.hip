@@ -740,11 +740,25 @@ __global__ __launch_bounds__(256) void k_qubo_anneal(SaArgs p) {
                 const size_t tb = (size_t)(on ? t : 0) * nmax;
                 const uint64_t* infp = m.info + tb;
                 const int blocks = (nb + C - 1) / C;
+                // LDS address of word x of this replica's masks = mbase + 4 x: one v_mad_u32_u16 from either half of a
+                // packed pair of word indices
+                typedef __attribute__((address_space(3))) uint32_t lds_word;
+                const uint32_t mbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)mask;
+                auto word_lo = [&](uint32_t packed) {
+                    uint32_t a;
+                    asm("v_mad_u32_u16 %0, %1, 4, %2 op_sel:[0,0,0,0]" : "=v"(a) : "v"(packed), "v"(mbase));
+                    return *(lds_word*)(uintptr_t)a;
+                };
+                auto word_hi = [&](uint32_t packed) {
+                    uint32_t a;
+                    asm("v_mad_u32_u16 %0, %1, 4, %2 op_sel:[1,0,0,0]" : "=v"(a) : "v"(packed), "v"(mbase));
+                    return *(lds_word*)(uintptr_t)a;
+                };
                 for (int mb = 0; mb < blocks; ++mb) {
+                    // the lane walks the block's qubits in turn, starting lj short of its end: i = mb C + (step - lj mod C)
+                    const int lo = mb * C, hi = lo + C;
+                    int i = lj == 0 ? lo : hi - lj;
                     for (int step = 0; step < C; ++step) {
-                        int rel = step - lj;
-                        rel += (rel >> 31) & C;
-                        const int i = mb * C + rel;
                         if (on && i < n) {
                             const uint32_t w = mk[i];
                             // packed per-qubit record: degree | word of the first partner | word of the same
@@ -755,8 +769,8 @@ __global__ __launch_bounds__(256) void k_qubo_anneal(SaArgs p) {
                             const int dg = (int)(ilo & 0xFFu);
                             // the three words this proposal looks at besides its own: the first partner's, the same
                             // qubit's in the two neighbouring slices ("none" is a word that stays zero): read together
-                            const uint32_t pw = mask[ilo >> 16];
-                            const uint32_t o1 = mask[ihi & 0xFFFFu], o2 = mask[ihi >> 16];
+                            const uint32_t pw = word_hi(ilo);
+                            const uint32_t o1 = word_lo(ihi), o2 = word_hi(ihi);
                             int lap;
                             if (dg <= 1) {
                                 lap = dg - 2 * (int)((uint32_t)dg & (pw >> lj));
@@ -773,19 +787,20 @@ __global__ __launch_bounds__(256) void k_qubo_anneal(SaArgs p) {
                             for (int kpl = 0; kpl < kHopPlanes; ++kpl)
                                 if (kpl < nplanes)
                                     mv += (__popc(o1 & prow[kpl]) + __popc(o2 & pcol[kpl])) << kpl;
-                            const int bit = (w >> lj) & 1u;
-                            const int d = 1 - 2 * bit;
+                            const int neg = __builtin_amdgcn_sbfe((int)w, (uint32_t)lj, 1u);  // -1 if the bit is set (the flip clears it), else 0
                             const int Ai = __popc(w);
-                            // 4 d (2 (Ai - 1) + d) + 4 d (2 L + d) + 10 d (lap + mv) with d = +-1 (d d = 1), without a
-                            // full 32-bit multiply: 8 + d (8 (Ai - 1 + L) + 10 (lap + mv))
+                            // 4 d (2 (Ai - 1) + d) + 4 d (2 L + d) + 10 d (lap + mv) with d = +-1 (d d = 1):
+                            // 8 + d (8 (Ai - 1 + L) + 10 (lap + mv)); the negation as xor and subtract
                             const int sl = ((Ai - 1 + L) << 3) + __mul24(10, lap + mv);
-                            const int dE = 8 + (bit ? -sl : sl);
+                            const int dE = ((sl ^ neg) - neg) + 8;
                             if (metropolis(dE, beta, rng)) {
                                 mk[i] = w ^ (1u << lj);
-                                L += d;
+                                L += 1 + 2 * neg;
                                 dEsum += dE;
                             }
                         }
+                        ++i;
+                        if (i == hi) i = lo;
                     }
                 }
                 if (on) {
