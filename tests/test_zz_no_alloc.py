@@ -33,6 +33,10 @@ CASES = [
     [(1024, 40, 64, 6, True), (40, 9, 8, 3, True)],
     [(2048, 12, 100, 4, False), (300, 5, 16, 1, False)],
     [(500, 33, 256, 5, False), (1024, 3, 256, 1, True)],
+    # short rows, 64 partitions or more: four partitions per wave step, a quad summed from the parts several waves
+    # left in the scratch (long partitions: a run per wave; few steps in all: a run per step)
+    [(63, 498, 64, 130, False), (40, 700, 20, 65, True)],
+    [(195, 73, 33, 386, False), (18, 138, 16, 700, False)],
 ]
 
 
