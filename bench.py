@@ -710,6 +710,12 @@ def main():
             if tr and (tr.get("Q"), tr.get("T"), tr.get("B"), tr.get("source")) == (Q, ir.T, B, args.source):
                 v["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
                 v["roofline"]["traffic_source"] = tr.get("profile")
+        for row in shipped_cost or []:  # the same for the shipped circuits' launches (keyed by config, case and batch)
+            tr = measured.get("shipped:" + row["config"])
+            if tr and (tr.get("case"), tr.get("partitions")) == (row["case"], row["partitions"]):
+                row["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+                row["roofline"]["traffic_source"] = tr.get("profile")
+                row["roofline"]["kernel"] = tr.get("kernel")
         by_w = {}
         for v in [primary] + others:
             key = ("uniform_fp64_table" if v["dtype"] == "f64" else
