@@ -642,7 +642,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 6 : 4) void k_cost_v3_gro
 constexpr int kGroups4Threads = 512;
 constexpr int kGroups4Ahead = QP_GROUPS4_AHEAD;
 
-template <int KIND, int TABMODE, int AHEAD>
+template <int KIND, int TABMODE, int AHEAD, bool ONE>
 __global__ __launch_bounds__(kGroups4Threads, 4) void k_cost_v3_groups4(V3Args p) {
     extern __shared__ __align__(16) uint8_t smem[];
     using E = typename Tab<KIND>::elem;
@@ -671,9 +671,12 @@ __global__ __launch_bounds__(kGroups4Threads, 4) void k_cost_v3_groups4(V3Args p
         e0 = *(lds_rep*)(uintptr_t)a0;
         e1 = *(lds_rep*)(uintptr_t)a1;
     };
-    const uint32_t strip_words = (uint32_t)(G + 1) * (uint32_t)ldq;
-    uint32_t* rows = reinterpret_cast<uint32_t*>(smem + tab_off) + (size_t)wave * strip_words + ldq;  // word (row, q) of the step
-    const uint32_t rbase = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_u8*)smem + tab_off + ((uint32_t)wave * strip_words + (uint32_t)ldq) * 4u);
+    // ONE (rows of 513 to 1024 bytes, one row per step): a lane's piece of the row before is what the lane itself held a
+    // step earlier, so it stays in registers and the strip is the one row
+    const uint32_t before_words = ONE ? 0u : (uint32_t)ldq;
+    const uint32_t strip_words = (uint32_t)G * (uint32_t)ldq + before_words;
+    uint32_t* rows = reinterpret_cast<uint32_t*>(smem + tab_off) + (size_t)wave * strip_words + before_words;  // word (row, q) of the step
+    const uint32_t rbase = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_u8*)smem + tab_off + ((uint32_t)wave * strip_words + before_words) * 4u);
     const bool lane_on = lane < G * lpr;
     const int lrow = lane_on ? lane / lpr : 0;
     const int lq0 = lane_on ? (lane - lrow * lpr) * 16 : 0;
@@ -796,14 +799,20 @@ __global__ __launch_bounds__(kGroups4Threads, 4) void k_cost_v3_groups4(V3Args p
         }
     };
 
-    if (s >= 1 && lane < lpr) {  // the part starts inside a partition: the row before its first
+    uint32_t last[ONE ? 16 : 1] = {};  // ONE: the lane's piece of the row before, as the strip would hold it
+    if (s >= 1 && (ONE ? lane_on : lane < lpr)) {  // the part starts inside a partition: the row before its first
         uint4 x[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g)
             x[g] = ids(*reinterpret_cast<const uint4*>(part_base(cq, g) + (size_t)(s * G - 1) * ldq + lane * 16));
         uint32_t o[16];
         interleave(x, o);
-        park(o, lane * 16 - ldq);
+        if constexpr (ONE) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) last[j] = o[j];
+        } else {
+            park(o, lane * 16 - ldq);
+        }
     }
     uint4 ring[AHEAD][4];
     uint32_t gring[AHEAD][kRowEdgeChunks];
@@ -833,18 +842,26 @@ __global__ __launch_bounds__(kGroups4Threads, 4) void k_cost_v3_groups4(V3Args p
             // are in flight together; a qubit that stayed looks up the zero diagonal)
             const int row = s * G + lrow;
             const bool mv = lane_on && row >= 2 && row < p.T;
-            const int before = lane_off - ldq;  // the same piece one row earlier
             uint32_t prv[16];
+            if constexpr (ONE) {
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const uint4 v = *reinterpret_cast<const uint4*>(rows + quarter(before, w));
-                prv[4 * w] = v.x;
-                prv[4 * w + 1] = v.y;
-                prv[4 * w + 2] = v.z;
-                prv[4 * w + 3] = v.w;
+                for (int j = 0; j < 16; ++j) {
+                    prv[j] = last[j];
+                    last[j] = cur[j];
+                }
+            } else {
+                const int before = lane_off - ldq;  // the same piece one row earlier
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(rows + quarter(before, w));
+                    prv[4 * w] = v.x;
+                    prv[4 * w + 1] = v.y;
+                    prv[4 * w + 2] = v.z;
+                    prv[4 * w + 3] = v.w;
+                }
+                // the group's last row is "the row before" of the next step (after every lane has read its own)
+                if (last_row) park(cur, lq0 - ldq);
             }
-            // the group's last row is "the row before" of the next step (after every lane has read its own)
-            if (last_row) park(cur, lq0 - ldq);
 #pragma unroll
             for (int j = 0; j < 16; j += 2) {
                 if (mv && ((prv[j] ^ cur[j]) | (prv[j + 1] ^ cur[j + 1])) != 0) {
@@ -3131,11 +3148,16 @@ int slice_cost_v3_impl(const char* fn, const QpCircuit* circ, const QpDTable* dt
     // look-ups never collide (2.85 -> 3.7 TB/s; an fp64 table of that size gains nothing over the four-partition kernel).
     const bool one_row_groups = narrow && ldq > 512 && dt->C <= 16 && dt->kind == QP_DT_U16 && !dt->grid.valid &&
                                 circ->edges_sched && circ->sched_ptr && circ->nE > 0;
-    if (one_row_groups ||
+    // The same rows, any table of at most 64 cores without a closed form, 64 partitions or more: the four-partition kernel
+    // of the short rows with one row per step (its small table forms leave room for sixteen waves per CU where the
+    // table at a pitch of 256 entries leaves room for eight).
+    const bool one_row_quads = narrow && ldq > 512 && dt->C <= 64 && !has_grid_form(dt) && B >= 64 && circ->edges_sched &&
+                               circ->sched_ptr && circ->nE > 0;
+    if (one_row_groups || one_row_quads ||
         (narrow && ldq <= 512 && circ->group_sched && circ->group_ptr && circ->group_ldq == ldq && circ->nE > 0)) {
         // rows of at most 512 bytes with the grouped gate list: whole groups of G slices per item, long items
         V3Args q = p;
-        if (one_row_groups) {
+        if (one_row_groups || one_row_quads) {
             q.gsched = circ->edges_sched;
             q.gptr = circ->sched_ptr;
         }
@@ -3214,8 +3236,8 @@ int slice_cost_v3_impl(const char* fn, const QpCircuit* circ, const QpDTable* dt
             }
             // LDS tables indexed by packed core pairs, 64 partitions or more: four partitions per wave step (a last
             // quad that is not full repeats a partition, which is at most 5 % more work from 64 partitions on)
-            const size_t strips4 = (size_t)(kGroups4Threads / kWave) * (G + 1) * ldq * 4;
-            if (!one_row_groups && B >= 64 && (mode == kTabLdsRep4 || mode == kTabLdsRep6 || mode == kTabLds256) &&
+            const size_t strips4 = (size_t)(kGroups4Threads / kWave) * (G + (one_row_quads ? 0 : 1)) * ldq * 4;
+            if ((one_row_quads || !one_row_groups) && B >= 64 && (mode == kTabLdsRep4 || mode == kTabLdsRep6 || mode == kTabLds256) &&
                 tab_lds + strips4 <= (size_t)kLdsBytes) {
                 // The stream of (quad, step) is cut into runs: one per wave of the launch (all resident, every wave the
                 // same number of steps to within one) when a partition has more than 16 steps -- a quad is then summed in
@@ -3225,8 +3247,9 @@ int slice_cost_v3_impl(const char* fn, const QpCircuit* circ, const QpDTable* dt
                 q.parts_per_item = whole ? (int)steps_total : 1;
                 q.nitems = whole ? nquads : nquads * steps_total;
                 void (*kern4)(V3Args) = nullptr;
-#define QP_GROUPS4(MODE) (dt->kind == QP_DT_F64 ? k_cost_v3_groups4<QP_DT_F64, MODE, kGroups4Ahead> : k_cost_v3_groups4<QP_DT_U16, MODE, kGroups4Ahead>)
-                kern4 = mode == kTabLdsRep4 ? QP_GROUPS4(kTabLdsRep4) : mode == kTabLdsRep6 ? QP_GROUPS4(kTabLdsRep6) : QP_GROUPS4(kTabLds256);
+#define QP_GROUPS4(MODE, ONE) (dt->kind == QP_DT_F64 ? k_cost_v3_groups4<QP_DT_F64, MODE, kGroups4Ahead, ONE> : k_cost_v3_groups4<QP_DT_U16, MODE, kGroups4Ahead, ONE>)
+                if (one_row_quads) kern4 = mode == kTabLdsRep4 ? QP_GROUPS4(kTabLdsRep4, true) : QP_GROUPS4(kTabLdsRep6, true);
+                else kern4 = mode == kTabLdsRep4 ? QP_GROUPS4(kTabLdsRep4, false) : mode == kTabLdsRep6 ? QP_GROUPS4(kTabLdsRep6, false) : QP_GROUPS4(kTabLds256, false);
 #undef QP_GROUPS4
                 const size_t lds4 = tab_lds + strips4;
                 const int waves4 = kGroups4Threads / kWave;
