@@ -3176,10 +3176,11 @@ int slice_cost_v3_impl(const char* fn, const QpCircuit* circ, const QpDTable* dt
         q.nitems = (int64_t)gchunks * q.nbgroups;
         const size_t gstrips = (size_t)kV3Waves * (G + 1) * ldq;
         if (dt->kind == QP_DT_F64 && dt->symmetric && dt->C >= 2 && tab_padded + gstrips > (size_t)kLdsBytes &&
-            !has_grid_form(dt) && (int64_t)T * ldq >= 32768) {
-            // fp64 table too large for LDS, symmetric to rounding, partitions of 32 KB or more: pair counts, a
+            !has_grid_form(dt) && (int64_t)T * ldq >= 24576) {
+            // fp64 table too large for LDS, symmetric to rounding, partitions of 24 KB or more: pair counts, a
             // workgroup per item (about 8 items per workgroup: every item ends with a pass over all counters, which
-            // costs as much as counting 30 KB of rows; below that size the gathers from device memory are no slower)
+            // costs as much as counting 30 KB of rows; measured on 256 cores: 31 KB partitions 0.69 TB/s against 0.55
+            // through gathers from device memory, 16 KB partitions 0.44 against 0.54)
             V3Args c = p;
             const int64_t want = (steps_total * B + (int64_t)cus * 8 - 1) / ((int64_t)cus * 8);
             const int64_t cspi = std::min<int64_t>(steps_total, std::max<int64_t>(2 * kV3Waves, want));

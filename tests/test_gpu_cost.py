@@ -198,7 +198,7 @@ SHORT_ROWS = [  # Q, T, C, B, integer weights, pmove: rows of 16 to 512 bytes (1
     (9, 700, 8, 5, True, 0.5), (30, 333, 16, 6, False, 0.3), (40, 6100, 20, 3, True, 0.2), (70, 150, 64, 9, False, 0.9),
     (128, 77, 100, 4, False, 0.5), (130, 200, 256, 3, True, 0.5), (260, 1300, 200, 2, False, 0.1), (500, 64, 130, 5, False, 1.0),
     (512, 3, 256, 4, True, 1.0), (18, 138, 16, 700, False, 0.3),
-    # fp64 tables too large for LDS on partitions of 32 KB or more: core pairs are counted
+    # fp64 tables too large for LDS on partitions of 24 KB or more: core pairs are counted
     (64, 500, 256, 4, False, 0.9), (512, 700, 144, 3, False, 0.4), (100, 5000, 180, 2, False, 0.05),
     # ... and on shorter partitions: gathers from device memory
     (60, 90, 150, 3, False, 0.5),
