@@ -2059,6 +2059,178 @@ __global__ __launch_bounds__(kV3Threads) void k_cost_v3_grid_row(V3Args p) {
     }
 }
 
+// Closed-form distances on rows of 1040 to 2048 bytes (NP = 2): k_cost_v3_grid_row with NP 1 KB pieces of the row per wave (a
+// lane holds piece (i * 64 + lane) of 16 bytes for i < NP, so every load instruction reads 1 KB in a row), the whole
+// row parked in the wave's strip for the gate gathers, the row before in registers: no barrier, no workgroup-wide
+// step.  Only the row's last piece can be ragged or missing for some lanes; which i that is, is the same for the
+// whole wave.  The first 8 gate chunks of a row are loaded together with it (the gate list is readable 8 chunks past
+// its end), two rows ahead.
+constexpr int kGridNThreads = 512;
+
+template <bool WRAP, int NP>
+__global__ __launch_bounds__(kGridNThreads) void k_cost_v3_grid_rown(V3Args p) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    constexpr int AHEAD = 2;
+    constexpr int kWavesN = kGridNThreads / kWave;
+    constexpr int NG = 8;  // gate chunks that travel with a row
+    static_assert(NG * QP_SCHED_CHUNK <= QP_SCHED_TAIL, "the prefetched chunks of the last slice stay inside the list's tail");
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int ldq = p.ldq;
+    const int npieces = ldq / 16;
+    const int i_last = (npieces - 1) / kWave, l_last = (npieces - 1) % kWave;  // the row's last piece
+    uint8_t* strip = smem + (size_t)wave * NP * 1024;
+    const bool on_last = lane <= l_last;  // the lane has a piece i_last
+    uint32_t keep[4];                     // byte masks of piece i_last: all ones except in the row's last piece
+    {
+        const int nvalid = lane == l_last ? p.Q - (npieces - 1) * 16 : 16;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int nb = min(4, max(0, nvalid - 4 * w));
+            keep[w] = !on_last ? 0u : nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u);
+        }
+    }
+    const uint32_t* sched_lane = p.edges_sched + lane;
+
+    for (int64_t it = (int64_t)blockIdx.x * kWavesN + wave; it < p.nitems; it += (int64_t)gridDim.x * kWavesN) {
+        const int chunk = (int)(it / p.B);
+        const int64_t b = it - (int64_t)chunk * p.B;
+        const int r0 = chunk * p.rows_per_item;
+        const int r1 = min(p.T, r0 + p.rows_per_item);
+        const uint8_t* base = p.A + (size_t)b * p.Tp * ldq;
+        uint32_t ax = 0, ay = 0;
+        GridAcc gacc;
+
+        // piece i of a row (a piece the lane does not have: the row's first bytes, masked away by keep)
+        auto fetch_piece = [&](int row, int i) -> uint4 {
+            const uint8_t* rp = base + (size_t)min(row, r1 - 1) * ldq;  // wave-uniform
+            const int off = (i < i_last || on_last) ? (i * kWave + lane) * 16 : 0;
+            return load_row16(rp + off);
+        };
+        auto fetch_gate = [&](int row, int c) -> uint32_t {
+            const uint32_t* gp = sched_lane + p.sptr[min(row, r1 - 1)];  // wave-uniform + lane
+            return gp[c * kWave];
+        };
+        // a row's words as they are compared: piece i_last masked, pieces past it absent
+        auto masked = [&](const uint4& v, int i, uint32_t (&o)[4]) {
+            o[0] = v.x;
+            o[1] = v.y;
+            o[2] = v.z;
+            o[3] = v.w;
+            if (i == i_last) {
+#pragma unroll
+                for (int w = 0; w < 4; ++w) o[w] &= keep[w];
+            }
+        };
+
+        uint32_t px[NP][4], py[WRAP ? 1 : NP][4];  // non-WRAP: x and y fields of the row before; WRAP: its masked words in px
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            uint32_t o[4] = {0, 0, 0, 0};
+            if (r0 >= 1 && i <= i_last) masked(fetch_piece(r0 - 1, i), i, o);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                px[i][w] = WRAP ? o[w] : o[w] & p.gxm;
+                if constexpr (!WRAP) py[i][w] = o[w] & p.gyi;
+            }
+        }
+        uint4 ring[AHEAD][NP];
+        uint32_t gring[AHEAD][NG];
+#pragma unroll
+        for (int k = 0; k < AHEAD; ++k) {
+#pragma unroll
+            for (int i = 0; i < NP; ++i) ring[k][i] = fetch_piece(r0 + k, min(i, i_last));
+#pragma unroll
+            for (int c = 0; c < NG; ++c) gring[k][c] = fetch_gate(r0 + k, c);
+        }
+
+        for (int g0 = r0; g0 < r1; g0 += AHEAD) {
+#pragma unroll
+            for (int k = 0; k < AHEAD; ++k) {
+                const int row = g0 + k;
+                if (row >= r1) break;
+                uint4 cur[NP];
+                uint32_t gates[NG];
+#pragma unroll
+                for (int i = 0; i < NP; ++i) cur[i] = ring[k][i];
+#pragma unroll
+                for (int c = 0; c < NG; ++c) gates[c] = gring[k][c];
+#pragma unroll
+                for (int i = 0; i < NP; ++i) ring[k][i] = fetch_piece(row + AHEAD, min(i, i_last));
+#pragma unroll
+                for (int c = 0; c < NG; ++c) gring[k][c] = fetch_gate(row + AHEAD, c);
+
+#pragma unroll
+                for (int i = 0; i < NP; ++i)
+                    if (i < i_last || (i == i_last && on_last)) *reinterpret_cast<uint4*>(strip + (i * kWave + lane) * 16) = cur[i];
+                const int s0 = p.sptr[row];
+                const int nch = (p.sptr[row + 1] - s0) / kWave;
+                // the row's gates, four chunks to a packed word of first and of second endpoints; a chunk the row does
+                // not have is (qubit 0, qubit 0)
+#pragma unroll
+                for (int c0 = 0; c0 < NG; c0 += 4) {
+                    if (c0 >= nch) break;
+                    uint32_t au[4], av[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const uint32_t g = c0 + c < nch ? gates[c0 + c] : 0u;
+                        au[c] = strip[g & 0xFFFFu];
+                        av[c] = strip[g >> 16];
+                    }
+                    const uint32_t U = au[0] | au[1] << 8 | au[2] << 16 | au[3] << 24;
+                    const uint32_t V = av[0] | av[1] << 8 | av[2] << 16 | av[3] << 24;
+                    if constexpr (WRAP) {
+                        gacc.add4(p, U, V);
+                    } else {
+                        ax = __builtin_amdgcn_sad_u8(U & p.gxm, V & p.gxm, ax);
+                        ay = __builtin_amdgcn_sad_u8(U & p.gyi, V & p.gyi, ay);
+                    }
+                }
+                for (int c = NG; c < nch; ++c) {
+                    const uint32_t g = sched_lane[s0 + c * kWave];
+                    const uint32_t U = strip[g & 0xFFFFu], V = strip[g >> 16];
+                    if constexpr (WRAP) {
+                        gacc.add4(p, U, V);
+                    } else {
+                        ax = __builtin_amdgcn_sad_u8(U & p.gxm, V & p.gxm, ax);
+                        ay = __builtin_amdgcn_sad_u8(U & p.gyi, V & p.gyi, ay);
+                    }
+                }
+                // movement: rows 2 .. r1 - 1, row before -> this row
+#pragma unroll
+                for (int i = 0; i < NP; ++i) {
+                    if (i > i_last) break;
+                    uint32_t cw[4];
+                    masked(cur[i], i, cw);
+                    if constexpr (WRAP) {
+                        if (row >= 2) {
+#pragma unroll
+                            for (int w = 0; w < 4; ++w) gacc.add4(p, px[i][w], cw[w]);
+                        }
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) px[i][w] = cw[w];
+                    } else {
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) {
+                            const uint32_t cx = cw[w] & p.gxm, cy = cw[w] & p.gyi;
+                            if (row >= 2) {
+                                ax = __builtin_amdgcn_sad_u8(px[i][w], cx, ax);
+                                ay = __builtin_amdgcn_sad_u8(py[i][w], cy, ay);
+                            }
+                            px[i][w] = cx;
+                            py[i][w] = cy;
+                        }
+                    }
+                }
+            }
+        }
+        double s;
+        if constexpr (WRAP) s = gacc.total(p);
+        else s = (double)p.gwx * wave_sum(ax) + (double)p.gwy * (wave_sum(ay) / (double)(1u << p.gxb));
+        if (lane == 0) p.partial[it] = s;
+    }
+}
+
 // Rows longer than 1024 bytes.  One workgroup of 16 waves owns an item.  Its threads form 1024 / P groups
 // (P = pieces of 16 bytes per row, rounded up to a power of two, at most 1024); a group takes a run of the
 // item's rows, thread j of it owns pieces j, j + 1024, ... (NP of them: 1 for rows up to 16 KB, kWidePieces
@@ -3434,6 +3606,31 @@ int slice_cost_v3_impl(const char* fn, const QpCircuit* circ, const QpDTable* dt
         kern<<<grid, kV3Threads, lds, stream>>>(p);
     } else {
         const bool gridpath = has_grid_form(dt);
+        if (gridpath && ldq <= 2048 && circ->edges_sched && circ->sched_ptr && circ->nE > 0) {
+            // closed form on rows of up to 2 KB: a wave per row, no workgroup-wide step (3.3 -> 4.7 TB/s, the rate of the
+            // 1 KB rows; four pieces per lane for rows of up to 4 KB need 154 registers and were slower than the
+            // workgroup-wide kernel below, 2.7 against 3.25 TB/s)
+            V3Args q = p;
+            if (int rc = fill_grid_args(q, dt)) return rc;
+            q.rows_per_item = rows_per_item_for(T, 1, B, cus);
+            const int32_t chunks = (T + q.rows_per_item - 1) / q.rows_per_item;
+            q.nitems = (int64_t)chunks * B;
+            if (int rc = need_workspace((size_t)q.nitems * sizeof(double))) return rc;
+            const bool wrap = dt->grid.wrap_x || dt->grid.wrap_y;
+            const int np = 2;
+            void (*kern)(V3Args) = wrap ? k_cost_v3_grid_rown<true, 2> : k_cost_v3_grid_rown<false, 2>;
+            const int waves = kGridNThreads / kWave;
+            const size_t lds = (size_t)waves * np * 1024;
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            int per_cu = 1;
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), kGridNThreads, lds));
+            const unsigned grid = (unsigned)std::min<int64_t>((int64_t)cus * std::max(per_cu, 1), (q.nitems + waves - 1) / waves);
+            kern<<<grid, kGridNThreads, lds, stream>>>(q);
+            HIP_TRY(hipGetLastError());
+            k_sum_chunks<<<(unsigned)((B + 255) / 256), 256, 0, stream>>>(q.partial, B, chunks, out, grid_scale_of(dt));
+            HIP_TRY(hipGetLastError());
+            return QP_OK;
+        }
         const bool one = ldq / 16 <= kV3Threads;  // one piece per thread
         const bool half = wide_threads < kV3Threads, two = wide_two, tab_lds = wide_tab > 0;
         const int threads = wide_threads;

@@ -796,6 +796,10 @@ WIDE = [  # Q, T, topology, nx, ny, integer weight (0 = uniform(1,3)), B, share 
     (20000, 7, "mesh", 4, 4, 2.0, 2, 0.2),       # four pieces per thread
     (30001, 4, "line", 7, 1, 0, 2, 0.2),
     (32767, 3, "mesh", 16, 16, 0, 1, 0.02),      # the longest row the circuit tables allow
+    # closed forms on rows of 1040 to 2048 bytes: a wave per row, two 1 KB pieces per lane; the last piece ragged, missing
+    # for most lanes, or full; rings
+    (1100, 50, "torus", 8, 8, 1.0, 3, 1.0), (1025, 9, "line", 16, 1, 3.0, 2, 0.5), (1999, 33, "mesh", 8, 4, 1.0, 70, 0.3),
+    (2040, 300, "mesh", 16, 16, 2.0, 4, 0.1),
 ]
 
 
