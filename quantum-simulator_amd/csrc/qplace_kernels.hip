@@ -3322,9 +3322,11 @@ int slice_cost_v3_impl(const char* fn, const QpCircuit* circ, const QpDTable* dt
                                 circ->edges_sched && circ->sched_ptr && circ->nE > 0;
     // The same rows, any table of at most 64 cores without a closed form, 64 partitions or more: the four-partition kernel
     // of the short rows with one row per step (its small table forms leave room for sixteen waves per CU where the
-    // table at a pitch of 256 entries leaves room for eight).
-    const bool one_row_quads = narrow && ldq > 512 && dt->C <= 64 && !has_grid_form(dt) && B >= 64 && circ->edges_sched &&
-                               circ->sched_ptr && circ->nE > 0;
+    // table at a pitch of 256 entries leaves room for eight).  16-bit tables of up to 96 cores too: at a pitch of 256
+    // they take at most 48 KB, two workgroups still fit (81 cores: 1.58 -> 1.33 ms on the benchmark's rows); beyond
+    // that one workgroup fits either way and k_cost_v3_row4 is the faster of the two (256 cores: 1.20 against 1.25 ms).
+    const bool one_row_quads = narrow && ldq > 512 && (dt->C <= 64 || (dt->kind == QP_DT_U16 && dt->C <= 96)) && !has_grid_form(dt) &&
+                               B >= 64 && circ->edges_sched && circ->sched_ptr && circ->nE > 0;
     if (one_row_groups || one_row_quads ||
         (narrow && ldq <= 512 && circ->group_sched && circ->group_ptr && circ->group_ldq == ldq && circ->nE > 0)) {
         // rows of at most 512 bytes with the grouped gate list: whole groups of G slices per item, long items
@@ -3421,7 +3423,7 @@ int slice_cost_v3_impl(const char* fn, const QpCircuit* circ, const QpDTable* dt
                 q.nitems = whole ? nquads : nquads * steps_total;
                 void (*kern4)(V3Args) = nullptr;
 #define QP_GROUPS4(MODE, ONE) (dt->kind == QP_DT_F64 ? k_cost_v3_groups4<QP_DT_F64, MODE, kGroups4Ahead, ONE> : k_cost_v3_groups4<QP_DT_U16, MODE, kGroups4Ahead, ONE>)
-                if (one_row_quads) kern4 = mode == kTabLdsRep4 ? QP_GROUPS4(kTabLdsRep4, true) : QP_GROUPS4(kTabLdsRep6, true);
+                if (one_row_quads) kern4 = mode == kTabLdsRep4 ? QP_GROUPS4(kTabLdsRep4, true) : mode == kTabLdsRep6 ? QP_GROUPS4(kTabLdsRep6, true) : QP_GROUPS4(kTabLds256, true);
                 else kern4 = mode == kTabLdsRep4 ? QP_GROUPS4(kTabLdsRep4, false) : mode == kTabLdsRep6 ? QP_GROUPS4(kTabLdsRep6, false) : QP_GROUPS4(kTabLds256, false);
 #undef QP_GROUPS4
                 const size_t lds4 = tab_lds + strips4;

@@ -320,7 +320,7 @@ def test_cost_v3_many_short_partitions(gpu, Q, T, C, B, integer):
 
 GROUPED = [  # Q, T, C, B, integer weights: rows over 512 bytes, table in LDS at pitch 256, 64 partitions or more
     (1000, 70, 256, 67, True), (1024, 9, 64, 64, False), (600, 41, 40, 130, False), (513, 3, 200, 65, True),
-    (777, 2, 64, 66, False), (1024, 1, 256, 64, True),
+    (777, 2, 64, 66, False), (1024, 1, 256, 64, True), (900, 30, 81, 70, True), (1024, 12, 96, 64, True), (640, 25, 97, 65, True),
 ]
 
 
