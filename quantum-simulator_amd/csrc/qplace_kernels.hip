@@ -80,6 +80,19 @@ __device__ inline uint32_t stage_table_pitch256(uint8_t* smem, const void* table
     return (uint32_t)(C * 256 * sizeof(E));
 }
 
+// The same at a pitch of 128 entries (up to 128 cores): rows 0 .. C - 1 only.
+template <typename E>
+__device__ inline uint32_t stage_table_pitch128(uint8_t* smem, const void* table, int C) {
+    const E* src = static_cast<const E*>(table);
+    E* dst = reinterpret_cast<E*>(smem);
+    for (int k = threadIdx.x; k < C * 128; k += blockDim.x) {
+        const int r = k >> 7, c = k & 127;
+        dst[k] = c < C ? src[r * C + c] : E(0);
+    }
+    __syncthreads();
+    return (uint32_t)(C * 128 * sizeof(E));
+}
+
 // Small tables, every entry stored 2^rep_shift times side by side (16-bit entries widened to 32 bits): a lane
 // reads copy (lane & (copies - 1)), so the lanes of an instruction that use different copies can never meet in a
 // bank, whatever entries they want.  With 32 copies (up to 16 cores) no look-up ever waits for another; with 8 or 4
@@ -129,6 +142,7 @@ constexpr int kTabLdsBand = 3; // LDS holds rows [band_lo, band_lo + band_rows) 
 constexpr int kTabGrid = 4;    // no table: the distance is a grid metric computed from the two core ids
 constexpr int kTabLdsRep4 = 6;  // LDS, up to 16 cores: index = from << 4 | to, every entry stored R times side by side
 constexpr int kTabLdsRep6 = 7;  // LDS, up to 64 cores: index = from << 6 | to, likewise (k_cost_v3_groups)
+constexpr int kTabLdsP128 = 8;  // LDS, up to 128 cores: index = from << 7 | to, one copy of rows 0 .. C - 1 (k_cost_v3_groups4, fp64)
 constexpr int kTabPairs = 5;   // no look-ups: unordered core pairs are counted in LDS and multiplied by the symmetrised
                                // table once per item (fp64 tables too large for LDS; k_cost_v3_pairs, k_cost_v3_wide)
 
@@ -648,15 +662,18 @@ __global__ __launch_bounds__(kGroups4Threads, 4) void k_cost_v3_groups4(V3Args p
     using E = typename Tab<KIND>::elem;
     using Acc = typename Tab<KIND>::acc;
     static_assert(kRowEdgeChunks == 4, "four gate chunks per step are prefetched");
-    static_assert(TABMODE == kTabLds256 || TABMODE == kTabLdsRep4 || TABMODE == kTabLdsRep6, "LDS tables indexed by packed core pairs");
+    static_assert(TABMODE == kTabLds256 || TABMODE == kTabLdsRep4 || TABMODE == kTabLdsRep6 || TABMODE == kTabLdsP128,
+                  "LDS tables indexed by packed core pairs");
+    static_assert(TABMODE != kTabLdsP128 || KIND == QP_DT_F64, "a 16-bit table of up to 128 cores is no larger at a pitch of 256 entries");
     constexpr int kWaves = kGroups4Threads / kWave;
-    constexpr uint32_t kIdBits = TABMODE == kTabLdsRep4 ? 0x0F0F0F0Fu : TABMODE == kTabLdsRep6 ? 0x3F3F3F3Fu : 0xFFFFFFFFu;
-    constexpr int kIdShift = TABMODE == kTabLdsRep6 ? 2 : 0;
+    constexpr uint32_t kIdBits = TABMODE == kTabLdsRep4 ? 0x0F0F0F0Fu : TABMODE == kTabLdsRep6 ? 0x3F3F3F3Fu : TABMODE == kTabLdsP128 ? 0x7F7F7F7Fu : 0xFFFFFFFFu;
+    constexpr int kIdShift = TABMODE == kTabLdsRep6 ? 2 : TABMODE == kTabLdsP128 ? 1 : 0;  // ids are stored times 1 << kIdShift
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     uint32_t tab_off;
     if constexpr (TABMODE == kTabLds256) tab_off = stage_table_pitch256<E>(smem, p.table, p.C);
     else if constexpr (TABMODE == kTabLdsRep4) tab_off = stage_table_replicated<E, 4>(smem, p.table, p.C, p.rep_shift);
+    else if constexpr (TABMODE == kTabLdsP128) tab_off = stage_table_pitch128<E>(smem, p.table, p.C);
     else tab_off = stage_table_replicated<E, 6>(smem, p.table, p.C, p.rep_shift);
     using RepE = typename std::conditional<sizeof(E) == 2, uint32_t, E>::type;  // a stored copy of an entry
     typedef __attribute__((address_space(3))) const RepE lds_rep;
@@ -686,7 +703,7 @@ __global__ __launch_bounds__(kGroups4Threads, 4) void k_cost_v3_groups4(V3Args p
     // Core ids as the strip holds them: bytes past the row's last qubit cleared (they then never differ between rows
     // and look up the zero diagonal), ids cut to the table's range, and for tables of up to 64 cores ids times four:
     // the halves (from / 4) << 8 | to of a packed pair are then (from << 6 | to) << 2, a multiple of the entry index, and
-    // one v_mad_u32_u16 turns a half into an address.
+    // one v_mad_u32_u16 turns a half into an address (up to 128 cores: ids times two, (from << 7 | to) << 1).
     uint32_t keep[4];
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
@@ -734,8 +751,8 @@ __global__ __launch_bounds__(kGroups4Threads, 4) void k_cost_v3_groups4(V3Args p
                 const uint32_t k = (from << 4) | to;  // from << 4 | to, a byte each
                 rep_at_halves(__builtin_amdgcn_perm(0u, k, 0x0c010c00u), e0, e1);
                 rep_at_halves(__builtin_amdgcn_perm(0u, k, 0x0c030c02u), e2, e3);
-            } else {  // ids times four: with the source ids shifted back a half is four times from << 6 | to
-                const uint32_t f = from >> 2;
+            } else {  // ids times 2^kIdShift: with the source ids shifted back a half is that many times the entry index
+                const uint32_t f = from >> kIdShift;
                 rep_at_halves(__builtin_amdgcn_perm(f, to, 0x05010400u), e0, e1);
                 rep_at_halves(__builtin_amdgcn_perm(f, to, 0x07030602u), e2, e3);
             }
@@ -3325,7 +3342,7 @@ int slice_cost_v3_impl(const char* fn, const QpCircuit* circ, const QpDTable* dt
     // table at a pitch of 256 entries leaves room for eight).  16-bit tables of up to 96 cores too: at a pitch of 256
     // they take at most 48 KB, two workgroups still fit (81 cores: 1.58 -> 1.33 ms on the benchmark's rows); beyond
     // that one workgroup fits either way and k_cost_v3_row4 is the faster of the two (256 cores: 1.20 against 1.25 ms).
-    const bool one_row_quads = narrow && ldq > 512 && (dt->C <= 64 || (dt->kind == QP_DT_U16 && dt->C <= 96)) && !has_grid_form(dt) &&
+    const bool one_row_quads = narrow && ldq > 512 && (dt->C <= 64 || (dt->kind == QP_DT_U16 ? dt->C <= 96 : dt->C <= 128)) && !has_grid_form(dt) &&
                                B >= 64 && circ->edges_sched && circ->sched_ptr && circ->nE > 0;
     if (one_row_groups || one_row_quads ||
         (narrow && ldq <= 512 && circ->group_sched && circ->group_ptr && circ->group_ldq == ldq && circ->nE > 0)) {
@@ -3412,8 +3429,17 @@ int slice_cost_v3_impl(const char* fn, const QpCircuit* circ, const QpDTable* dt
             // LDS tables indexed by packed core pairs, 64 partitions or more: four partitions per wave step (a last
             // quad that is not full repeats a partition, which is at most 5 % more work from 64 partitions on)
             const size_t strips4 = (size_t)(kGroups4Threads / kWave) * (G + (one_row_quads ? 0 : 1)) * ldq * 4;
-            if ((one_row_quads || !one_row_groups) && B >= 64 && (mode == kTabLdsRep4 || mode == kTabLdsRep6 || mode == kTabLds256) &&
-                tab_lds + strips4 <= (size_t)kLdsBytes) {
+            int mode4 = mode;  // the table form of the four-partition kernel
+            size_t tab4 = tab_lds;
+            if (!gridpath && dt->kind == QP_DT_F64 && dt->C > 64 && dt->C <= 128) {
+                // fp64 tables of 65 to 128 cores: at a pitch of 128 entries (a form the one-partition kernel does not have)
+                mode4 = kTabLdsP128;
+                tab4 = (size_t)dt->C * 128 * sizeof(double);
+            }
+            if ((one_row_quads || !one_row_groups) && B >= 64 &&
+                (mode4 == kTabLdsRep4 || mode4 == kTabLdsRep6 || mode4 == kTabLds256 || mode4 == kTabLdsP128) &&
+                tab4 + strips4 <= (size_t)kLdsBytes) {
+                if (mode4 == kTabLdsP128) q.rep_shift = 0;
                 // The stream of (quad, step) is cut into runs: one per wave of the launch (all resident, every wave the
                 // same number of steps to within one) when a partition has more than 16 steps -- a quad is then summed in
                 // parts -- else runs of a few whole quads.
@@ -3423,10 +3449,11 @@ int slice_cost_v3_impl(const char* fn, const QpCircuit* circ, const QpDTable* dt
                 q.nitems = whole ? nquads : nquads * steps_total;
                 void (*kern4)(V3Args) = nullptr;
 #define QP_GROUPS4(MODE, ONE) (dt->kind == QP_DT_F64 ? k_cost_v3_groups4<QP_DT_F64, MODE, kGroups4Ahead, ONE> : k_cost_v3_groups4<QP_DT_U16, MODE, kGroups4Ahead, ONE>)
-                if (one_row_quads) kern4 = mode == kTabLdsRep4 ? QP_GROUPS4(kTabLdsRep4, true) : mode == kTabLdsRep6 ? QP_GROUPS4(kTabLdsRep6, true) : QP_GROUPS4(kTabLds256, true);
-                else kern4 = mode == kTabLdsRep4 ? QP_GROUPS4(kTabLdsRep4, false) : mode == kTabLdsRep6 ? QP_GROUPS4(kTabLdsRep6, false) : QP_GROUPS4(kTabLds256, false);
+                if (mode4 == kTabLdsP128) kern4 = one_row_quads ? k_cost_v3_groups4<QP_DT_F64, kTabLdsP128, kGroups4Ahead, true> : k_cost_v3_groups4<QP_DT_F64, kTabLdsP128, kGroups4Ahead, false>;
+                else if (one_row_quads) kern4 = mode4 == kTabLdsRep4 ? QP_GROUPS4(kTabLdsRep4, true) : mode4 == kTabLdsRep6 ? QP_GROUPS4(kTabLdsRep6, true) : QP_GROUPS4(kTabLds256, true);
+                else kern4 = mode4 == kTabLdsRep4 ? QP_GROUPS4(kTabLdsRep4, false) : mode4 == kTabLdsRep6 ? QP_GROUPS4(kTabLdsRep6, false) : QP_GROUPS4(kTabLds256, false);
 #undef QP_GROUPS4
-                const size_t lds4 = tab_lds + strips4;
+                const size_t lds4 = tab4 + strips4;
                 const int waves4 = kGroups4Threads / kWave;
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
                 int per_cu4 = 1;

@@ -253,6 +253,8 @@ SHORT_ROWS_QUADS = [  # Q, T, C, B, integer weights, pmove: short rows, an LDS t
     (63, 498, 64, 301, False, 1.0), (18, 138, 16, 9000, False, 0.05), (33, 1, 8, 64, True, 1.0), (33, 2, 8, 66, False, 1.0),
     # fewer steps in the whole batch than the GPU holds waves (a run per step, none without one)
     (195, 73, 33, 386, False, 1.0), (97, 1080, 2, 76, False, 1.0), (8, 6202, 48, 83, True, 0.02),
+    # fp64 tables of 65 to 128 cores: at a pitch of 128 entries
+    (63, 300, 100, 70, False, 1.0), (128, 77, 128, 64, False, 0.5), (40, 700, 65, 66, False, 0.3),
 ]
 
 
@@ -321,6 +323,7 @@ def test_cost_v3_many_short_partitions(gpu, Q, T, C, B, integer):
 GROUPED = [  # Q, T, C, B, integer weights: rows over 512 bytes, table in LDS at pitch 256, 64 partitions or more
     (1000, 70, 256, 67, True), (1024, 9, 64, 64, False), (600, 41, 40, 130, False), (513, 3, 200, 65, True),
     (777, 2, 64, 66, False), (1024, 1, 256, 64, True), (900, 30, 81, 70, True), (1024, 12, 96, 64, True), (640, 25, 97, 65, True),
+    (1024, 9, 100, 64, False), (600, 41, 128, 70, False), (900, 30, 65, 66, False),
 ]
 
 

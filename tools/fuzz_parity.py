@@ -132,7 +132,7 @@ def main():
             ldq = (Q + 15) // 16 * 16
             T = pick(1, max(1, min(9000, 300000 // ldq)))
             integer = bool(pick(0, 1))
-            C = pick(2, 256) if integer else pick(2, 64)
+            C = pick(2, 256) if integer else pick(2, 128)
             B = pick(64, 200) if T * ldq > 60000 else pick(64, 3000)
             return "cost_v3_short_rows_quads", TC.test_cost_v3_short_rows_four_partitions, (gpu, Q, T, C, B, integer, float(rng.choice([0.02, 0.3, 1.0])))
         if kind == 13:  # communication counts from the pair counters of the row walk: whole partitions or chunks
@@ -163,7 +163,7 @@ def main():
                                                                                 float(rng.choice([0.02, 0.3, 1.0])))
         if kind == 10:  # long rows, table in LDS, 64 partitions or more: four partitions per wave step
             integer = bool(pick(0, 1))
-            return "cost_v3_four_partitions", TC.test_cost_v3_four_partitions_per_wave, (gpu, pick(513, 1024), pick(1, 80), pick(2, 256) if integer else pick(2, 64),
+            return "cost_v3_four_partitions", TC.test_cost_v3_four_partitions_per_wave, (gpu, pick(513, 1024), pick(1, 80), pick(2, 256) if integer else pick(2, 128),
                                                                                          pick(64, 140), integer)
         if kind == 9:
             C = [4, 9, 16, 25][pick(0, 3)]
