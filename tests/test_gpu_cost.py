@@ -71,6 +71,43 @@ def test_cost_v3_golden(gpu, name):
 
 
 @pytest.mark.parametrize("name", ALL_CASES)
+def test_cost_v3_golden_in_large_batches(gpu, name):
+    """The reference's own partitions and costs through the kernels that only batches of 64 partitions or more reach
+    (four partitions per wave step): every fixture partition 67 times over, interleaved with the other placers'
+    partitions of the same length and with shuffled copies in between, so that the four partitions of a wave step
+    differ; every copy must cost what the reference's run of it cost."""
+    torch, engine, eng, dev = gpu
+    gc = load_case(name)
+    from quantum_simulator_amd.timeslices import CircuitIR
+    ir = CircuitIR(gc.Q, gc.gate_q, gc.gate_mr, slices=gc.slices)
+    dc = engine.DeviceCircuit(ir, dev)
+    dt = engine.DistanceTable(gc.D, dev)
+    exact = name.endswith("_i")
+    rng = np.random.default_rng(len(name))
+    by_len = {}
+    for p in ("HQA", "TRHQA", "GTRHQA"):
+        if gc.has(p):
+            by_len.setdefault(gc.part(p).shape[0], []).append(p)
+    for Tp, placers in by_len.items():
+        rows, want = [], []
+        for k in range(67):
+            for p in placers:
+                rows.append(_pad(gc.part(p), dc.ldq))
+                want.append(gc.cost(p))
+            noise = _pad(gc.part(placers[0]), dc.ldq).copy()  # a partition of the same shape with its rows shuffled
+            rng.shuffle(noise, axis=0)
+            rows.append(noise)
+            want.append(None)
+        A = torch.from_numpy(np.stack(rows)).to(dev)
+        nterms = ir.nE + ir.T * gc.Q
+        for table in ("packed", "table"):
+            got = eng.cost_v3(dc, dt, A, table=table).cpu().numpy()
+            for b, w in enumerate(want):
+                if w is not None:
+                    assert _close(got[b], w, exact, nterms), (table, b, got[b], w)
+
+
+@pytest.mark.parametrize("name", ALL_CASES)
 def test_cost_v2_v1_v4_golden(gpu, name):
     torch, engine, eng, dev = gpu
     gc = load_case(name)
